@@ -1,0 +1,49 @@
+/*
+ * oracle/lizard_oracle.h — TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C, single-threaded restatement of the Lizard block-compress path (reference inikep/lizard 1.0,
+ * 64-bit build), written from the behaviour of the reference, not from its text. It is the checker
+ * for the HIP path: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ * The product library (lizard_amd/csrc) never links, calls or falls back to anything in oracle/.
+ *
+ * Parity status: PINNED — tests/test_oracle.py checks this restatement (a) against the known-answer
+ * sums/XXH64 chains recorded from the compiled reference (tests/golden/) and (b), when
+ * oracle/_ref/ is present, byte-for-byte against the unmodified reference library built with
+ * -DLIZARD_RESET_MEM (zero-initialised match-finder state, reference lib/lizard_compress.c:329-332).
+ *
+ * Oracle definition: per-block output of Lizard_compress_extState() on a zero-filled
+ * state.  Supported levels: 10, 11, 30, 31 (fastSmall / fast + fastLZ4 codewords),
+ * 21, 22, 41, 42 (priceFast + LIZv1 codewords); levels >= 30 add the huff0 stage.
+ */
+#ifndef LIZARD_ORACLE_H
+#define LIZARD_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Lizard_compressBound (reference lib/lizard_compress.h:124). */
+int lzo_compress_bound(int srcSize);
+
+/* 1 if this oracle restates `level`, else 0. */
+int lzo_level_supported(int level);
+
+/* Lizard_compress_extState on a zero-filled state (reference lib/lizard_compress.c:583-593,472-547).
+ * Returns bytes written to dst, 0 on failure (dst too small, unsupported level/size). */
+int lzo_compress(const void* src, void* dst, int srcSize, int dstCapacity, int level);
+
+/* HUF_compress (reference lib/entropy/huf_compress.c:609): returns compressed size, 0 if not
+ * compressible, 1 for single-symbol RLE, or (size_t)-1 for the error cases that the caller treats as
+ * "store raw". */
+size_t lzo_huf_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize);
+
+/* RDG_genBuffer (reference programs/datagen.c:153): deterministic synthetic data. */
+void lzo_datagen(void* buffer, size_t size, double matchProba, double litProba, unsigned seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
