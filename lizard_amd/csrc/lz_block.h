@@ -1,0 +1,302 @@
+// lz_block.h — device-side Lizard block compression for ONE wavefront per API block (gfx950).
+//
+// What is implemented here (bit-exact with reference inikep/lizard 1.0, 64-bit build, zero-initialised
+// match-finder state — the oracle of SURVEY.md §0.2):
+//   * fastSmall / fast greedy parser   (reference lib/lizard_parser_fastsmall.h:34-189,
+//                                        lib/lizard_parser_fast.h:41-196)          levels 10/30, 11/31
+//   * fastLZ4 token encoder            (reference lib/lizard_compress_lz4.h:3-86)
+//   * sub-block container              (reference lib/lizard_compress.c:141-250, 472-547)
+//
+// How the serial parse is mapped onto a 64-lane wave (this is a re-design, not a translation):
+//   The reference walks one position at a time: hash, table get, table put, test candidate.  Between
+//   two accepted matches the positions it will visit are known in advance (the skip schedule of
+//   fast.h:75-82 restarts after every match), so ONE ROUND evaluates the next 64 visits at once:
+//     lane l -> visit v0+l -> position p, 8-byte load, hash5, LDS table read (old value).
+//   Two visits of one round can hit the same table slot; the reference would have shown the later
+//   one the earlier one's position.  A 1-byte-per-slot LDS tag array detects such rounds (every
+//   lane stores its lane id at tag[h] and reads it back); only then a short loop over the clashing
+//   hash values rebuilds, per lane, the mask of same-hash lanes, from which the in-order predecessor
+//   (and later the in-order LAST writer) follow with clz/ctz on ballot masks.
+//   Each lane then applies the reference's accept test to its candidate; the first accepting lane
+//   (ctz of the ballot) is the match the reference would have taken; lanes up to and including it
+//   commit their table puts, later lanes are discarded (the reference never reached them).
+//   Match extension (forward/backward) and the sequence encoder are wave-parallel byte operations.
+//   The reference's post-match probe of `ip` (fast.h:143-165) is folded into the next round as
+//   lane 0 ("special" lane), because with anchor == ip it is exactly a search visit that cannot
+//   extend backwards.
+//
+// All cross-lane traffic goes through lz_wave.h.  Variables documented "uniform" hold the same value
+// in every lane (they are derived from ballots/readlanes and live in SGPRs).
+#pragma once
+#include "lz_wave.h"
+
+#define LZ_SUBBLOCK       (1u << 17)        // LIZARD_BLOCK_SIZE, reference lib/lizard_compress.h:122
+#define LZ_SUBBLOCK_PAD   (LZ_SUBBLOCK + 32)
+#define LZ_EMPTY          0xFFFFFFFFu       // table entry that fails "e < cur" (reference state: 0 < lowLimit)
+#define LZ_MFLIMIT        20u               // MFLIMIT = WILDCOPYLENGTH + MINMATCH, lizard_common.h:77-79
+#define LZ_LASTLITERALS   16u
+#define LZ_MIN_OFFSET     8u                // LIZARD_FAST_MIN_OFFSET, lizard_parser_fast.h:1
+#define LZ_MAX_DIST_LZ4   65535u            // (1 << windowLog) - 1, windowLog 16, lizard_common.h:223,237
+
+// ---- per-wave stream staging (global-memory scratch; reference keeps these in Lizard_stream_t) ----
+struct LzStreams {
+    u8* lit;    u8* flags;  u8* off16;  u8* off24;      // scratch bases (each LZ_SUBBLOCK_PAD bytes)
+    u32 nlit;   u32 nflags; u32 noff16; u32 noff24;     // uniform byte counts of the current sub-block
+};
+#define LZ_SCRATCH_BYTES (4u * LZ_SUBBLOCK_PAD)
+
+LZ_DEV void lz_streams_bind(LzStreams& st, u8* scratch)
+{
+    st.lit = scratch; st.flags = scratch + LZ_SUBBLOCK_PAD;
+    st.off16 = scratch + 2 * LZ_SUBBLOCK_PAD; st.off24 = scratch + 3 * LZ_SUBBLOCK_PAD;
+    st.nlit = st.nflags = st.noff16 = st.noff24 = 0;
+}
+
+// 64-bit-build hash of the reference: hash5 over an 8-byte little-endian read
+// (reference lib/lizard_compress.c:77,90-91; chosen by lizard_parser_fastsmall.h:4-9 / fast.h:7-12).
+template <int HASHLOG>
+LZ_DEV u32 lz_hash5(u64 u) { return (u32)(((u * 889523592379ULL) << 24) >> (64 - HASHLOG)); }
+
+// Offset of visit v from the run start and the step taken after it, closed form of
+// "step = searchMatchNb++ >> Lizard_skipTrigger" (reference lizard_parser_fast.h:75-82):
+// s_0 = 1, s_v = (63+v)>>6, f(v) = sum_{j<v} s_j.
+LZ_DEV u32 lz_visit_off(u32 v)
+{
+    u32 q = (v - 1u) >> 6, t = (v - 1u) & 63u;
+    return v == 0 ? 0u : 1u + 32u * q * (q + 1u) + t * (q + 1u);
+}
+LZ_DEV u32 lz_visit_step(u32 v) { return v == 0 ? 1u : (63u + v) >> 6; }
+
+// Common-prefix length of src[a..] and src[b..] (b < a) with a+i < limit — reference
+// lib/lizard_common.h:475-490 (its 8/4/2/1-byte stepping is unobservable). 64 bytes per round.
+LZ_DEV u32 lz_count_fwd(const u8* src, u32 a, u32 b, u32 limit)
+{
+    const u32 lane = lz_lane();
+    u32 n = 0;                                              // uniform
+    for (;;) {
+        const u32 i = n + lane;
+        const bool eq = (a + i < limit) && (src[a + i] == src[b + i]);
+        const u64 ne = lz_ballot(!eq);
+        if (ne) return n + lz_ctz64(ne);
+        n += 64;
+    }
+}
+
+// Backward extension: largest k with P-i >= anchor, M-i >= 0 and src[P-i] == src[M-i] for 1<=i<=k
+// (reference lizard_parser_fast.h:102; lowPrefixPtr is the block start for independent blocks).
+LZ_DEV u32 lz_count_back(const u8* src, u32 P, u32 M, u32 anchor)
+{
+    const u32 lane = lz_lane();
+    u32 n = 0;                                              // uniform
+    for (;;) {
+        const u32 i = n + lane + 1u;
+        const bool eq = (P >= anchor + i) && (M >= i) && (src[P - i] == src[M - i]);
+        const u64 ne = lz_ballot(!eq);
+        if (ne) return n + lz_ctz64(ne);
+        n += 64;
+    }
+}
+
+// Wave-wide byte copy (all lanes call; n uniform). dst/src need no alignment.
+LZ_DEV void lz_copy(u8* dst, const u8* src, u32 n)
+{
+    const u32 lane = lz_lane();
+    const u32 n4 = n & ~3u;
+    for (u32 i = lane * 4u; i < n4; i += 256u) lz_st32(dst + i, lz_ld32(src + i));
+    for (u32 i = n4 + lane; i < n; i += 64u) dst[i] = src[i];
+}
+
+// Length escape shared by all codewords (reference lib/lizard_compress_lz4.h:21-23), as a packed
+// little-endian word + byte count: v<254 -> [v]; v<65536 -> [254, lo, hi]; else [255, b0, b1, b2].
+LZ_DEV void lz_len_ext(bool present, u32 v, u32& word, u32& nbytes)
+{
+    if (!present)          { word = 0; nbytes = 0; }
+    else if (v < 254u)     { word = v; nbytes = 1; }
+    else if (v < 65536u)   { word = 254u | (v << 8); nbytes = 3; }
+    else                   { word = 255u | (v << 8); nbytes = 4; }
+}
+
+// fastLZ4 sequence (reference lib/lizard_compress_lz4.h:3-71): token -> flags stream; literal-length
+// escape, literals, LE16 offset and match-length escape -> literals stream, as one contiguous record
+// whose bytes are produced 64 at a time, one per lane.
+LZ_DEV void lz_emit_lz4(const u8* src, u32 anchor, u32 P, u32 ml, u32 M, LzStreams& st)
+{
+    const u32 lane = lz_lane();
+    const u32 L = P - anchor, off = P - M, mlc = ml - 4u;
+    u32 extLw, extLn, extMw, extMn;
+    lz_len_ext(L >= 15u, L - 15u, extLw, extLn);
+    lz_len_ext(mlc >= 15u, mlc - 15u, extMw, extMn);
+    const u32 token = (L >= 15u ? 15u : L) | ((mlc >= 15u ? 15u : mlc) << 4);
+    const u32 oOff = extLn + L, oExtM = oOff + 2u, R = oExtM + extMn;
+    u8* out = st.lit + st.nlit;
+    for (u32 i = lane; i < R; i += 64u) {
+        u32 b;
+        if (i < extLn)       b = extLw >> (8u * i);
+        else if (i < oOff)   b = src[anchor + (i - extLn)];
+        else if (i < oExtM)  b = off >> (8u * (i - oOff));
+        else                 b = extMw >> (8u * (i - oExtM));
+        out[i] = (u8)b;
+    }
+    if (lane == 0) st.flags[st.nflags] = (u8)token;
+    st.nlit += R; st.nflags += 1u;
+}
+
+// Trailing literals of a sub-block (reference lib/lizard_compress_lz4.h:74-86): raw, no token.
+LZ_DEV void lz_emit_last_literals(const u8* src, u32 anchor, u32 E, LzStreams& st)
+{
+    lz_copy(st.lit + st.nlit, src + anchor, E - anchor);
+    st.nlit += E - anchor;
+}
+
+// ---- fastSmall / fast parser over one sub-block [S,E) of the block at `src` ----------------------
+// table: 2^HASHLOG u32 positions (block-relative), LZ_EMPTY when never written; persists across the
+//        sub-blocks of one block (reference lizard_compress.c:494-540).  LDS for HASHLOG 12.
+// tag:   2^TAGLOG bytes of LDS, contents irrelevant on entry.
+template <int HASHLOG, int TAGLOG>
+LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, u32* table, u8* tag, LzStreams& st)
+{
+    const u32 lane = lz_lane();
+    const u64 laneBit = 1ull << lane;
+    const u64 lanesBelow = laneBit - 1ull;
+    u32 anchor = S;                                                  // uniform
+    if (E - S < LZ_MFLIMIT + 1u) { lz_emit_last_literals(src, anchor, E, st); return; }   // fast.h:63
+    const u32 mflimit = E - LZ_MFLIMIT, matchlimit = E - LZ_LASTLITERALS;
+    // fast.h:57-58 in block-relative positions: lowLimit is fixed at sub-block entry
+    const u32 lowPos = S > LZ_MAX_DIST_LZ4 ? S - LZ_MAX_DIST_LZ4 : 0u;
+
+    if (lane == 0) table[lz_hash5<HASHLOG>(lz_ld64(src + S))] = S;   // fast.h:66
+    lz_wave_sync();
+
+    u32 ip = S + 1u;        // uniform: run start, or (special==1) the post-match probe position
+    u32 special = 0;        // uniform
+    for (;;) {
+        // ---------------- search: rounds of 64 visits until a lane accepts ----------------
+        u32 v0 = 0;         // uniform: visits consumed by earlier rounds of this run (incl. the special one)
+        u32 P = 0, M = 0;   // uniform: winner position and its candidate
+        for (;;) {
+            const u32 slot = v0 + lane;                 // slot 0 of a special run is the probe of `ip` itself
+            u32 p; bool valid;
+            if (special && slot == 0) { p = ip; valid = true; }          // caller guarantees ip <= mflimit (fast.h:143)
+            else {
+                const u32 v = slot - special;
+                p = ip + special + lz_visit_off(v);
+                valid = p + lz_visit_step(v) <= mflimit;                 // fast.h:84, tested before the probe
+            }
+            u32 h = 0, e = LZ_EMPTY, first4 = 0;
+            if (valid) {
+                const u64 bytes = lz_ld64(src + p);
+                first4 = (u32)bytes;
+                h = lz_hash5<HASHLOG>(bytes);
+                e = table[h];                                            // fast.h:86 (old value)
+                tag[h & ((1u << TAGLOG) - 1u)] = (u8)lane;
+            }
+            lz_wave_sync();
+            const bool lost = valid && tag[h & ((1u << TAGLOG) - 1u)] != (u8)lane;
+            u64 pend = lz_ballot(lost);                                  // uniform
+            u64 grp = laneBit;                                           // lanes of this round with my hash
+            if (pend) {
+                // rare-ish path: at least two valid lanes share a tag slot; rebuild exact hash groups
+                while (pend) {
+                    const u32 f = lz_ctz64(pend);
+                    const u32 hv = lz_readlane(h, f);
+                    const bool mine = valid && h == hv;
+                    const u64 g = lz_ballot(mine);
+                    if (mine) grp = g;
+                    pend &= ~g;
+                }
+                // in-order predecessor inside the round: the reference would have read ITS put
+                const u64 prev = grp & lanesBelow;
+                const u32 j = prev ? 63u - lz_clz64(prev) : lane;
+                const u32 pj = lz_shfl(p, j);
+                if (prev) e = pj;
+            }
+            // accept test, fast.h:90-97
+            bool ok = false;
+            if (valid && e >= lowPos && e < p && p - e <= LZ_MAX_DIST_LZ4 && p - e >= LZ_MIN_OFFSET)
+                ok = lz_ld32(src + e) == first4;
+            const u64 okMask = lz_ballot(ok);                            // uniform
+            const u64 validMask = lz_ballot(valid);                      // uniform, a prefix of lanes
+            u32 w = 0;
+            u64 commit = validMask;
+            if (okMask) { w = lz_ctz64(okMask); commit = validMask & (~0ull >> (63u - w)); }
+            // table puts in visit order: the last same-hash lane inside `commit` wins (fast.h:88)
+            if ((commit & laneBit) && (grp & commit & ~(lanesBelow | laneBit)) == 0) table[h] = p;
+            lz_wave_sync();
+            if (okMask) { P = lz_readlane(p, w); M = lz_readlane(e, w); break; }
+            if (validMask != ~0ull) goto tail;                           // ran into mflimit without a match
+            v0 += 64u;
+        }
+        // ---------------- extend, encode ----------------
+        {
+            u32 ml = 4u + lz_count_fwd(src, P + 4u, M + 4u, matchlimit); // fast.h:100
+            const u32 back = lz_count_back(src, P, M, anchor);           // fast.h:102 (0 when P == anchor)
+            P -= back; M -= back; ml += back;
+            lz_emit_lz4(src, anchor, P, ml, M, st);                      // fast.h:138
+            ip = P + ml; anchor = ip;
+        }
+        if (ip > mflimit) goto tail;                                     // fast.h:143
+        if (lane == 0) table[lz_hash5<HASHLOG>(lz_ld64(src + ip - 2u))] = ip - 2u;   // fast.h:146
+        lz_wave_sync();
+        special = 1u;                                                    // fast.h:149-165 == slot 0 of the next round
+    }
+tail:
+    lz_emit_last_literals(src, anchor, E, st);                           // fast.h:187-190
+}
+
+// ---- sub-block container (reference lib/lizard_compress.c:141-250) -------------------------------
+LZ_DEV void lz_st24(u8* p, u32 v) { p[0] = (u8)v; p[1] = (u8)(v >> 8); p[2] = (u8)(v >> 16); }
+
+// Raw stream: LE24 length + bytes (lizard_compress.c:176-182). Returns bytes written. All lanes call.
+LZ_DEV u32 lz_put_stream_raw(u8* op, const u8* stream, u32 n)
+{
+    if (lz_lane() == 0) lz_st24(op, n);
+    lz_copy(op + 3, stream, n);
+    return 3u + n;
+}
+
+// Lizard_writeBlock without the Huffman stage (levels < 30). `in` = first byte of the sub-block.
+// Returns the bytes written at `op` (uniform). The caller guarantees room for n + 4 bytes.
+LZ_DEV u32 lz_write_subblock_raw_streams(const u8* in, u32 n, u8* op, LzStreams& st)
+{
+    const u32 sum = st.nflags + st.nlit + st.noff16 + st.noff24;
+    const u32 total = 16u + sum;                              // header + 5 x LE24 + streams
+    // lizard_compress.c:201 and :228
+    const bool raw = st.nlit < LZ_LASTLITERALS || sum + 16u > n || total + total / 32u + 512u > n;
+    if (raw) {
+        if (lz_lane() == 0) { op[0] = 128; lz_st24(op + 1, n); }   // LIZARD_FLAG_UNCOMPRESSED, :239-244
+        lz_copy(op + 4, in, n);
+        return n + 4u;
+    }
+    lz_wave_sync();                                           // stream bytes written by other lanes
+    u8* q = op;
+    if (lz_lane() == 0) { q[0] = 0; lz_st24(q + 1, 0); }      // header byte, empty `len` stream (:203-207)
+    q += 4;
+    q += lz_put_stream_raw(q, st.off16, st.noff16);           // :209
+    q += lz_put_stream_raw(q, st.off24, st.noff24);           // :212
+    q += lz_put_stream_raw(q, st.flags, st.nflags);           // :215
+    q += lz_put_stream_raw(q, st.lit, st.nlit);               // :221
+    return total;
+}
+
+// ---- one API block: reference Lizard_compress_extState on a zeroed state (lizard_compress.c:583) ----
+// dst must have room for Lizard_compressBound(n) bytes. Returns the compressed size (uniform).
+template <int HASHLOG, int TAGLOG>
+LZ_DEV u32 lz_compress_block_fast(const u8* src, u32 n, u8* dst, u32 level, u32* table, u8* tag, u8* scratch)
+{
+    const u32 lane = lz_lane();
+    LzStreams st;
+    lz_streams_bind(st, scratch);
+    for (u32 i = lane; i < (1u << HASHLOG); i += 64u) table[i] = LZ_EMPTY;
+    lz_wave_sync();
+    if (lane == 0) dst[0] = (u8)level;                        // lizard_compress.c:488
+    u32 op = 1u;                                              // uniform
+    for (u32 pos = 0; pos < n; ) {                            // lizard_compress.c:494
+        const u32 part = (n - pos) < LZ_SUBBLOCK ? (n - pos) : LZ_SUBBLOCK;
+        st.nlit = st.nflags = st.noff16 = st.noff24 = 0;      // Lizard_initBlock, :130-138
+        lz_parse_fast<HASHLOG, TAGLOG>(src, pos, pos + part, table, tag, st);
+        op += lz_write_subblock_raw_streams(src + pos, part, dst + op, st);
+        lz_wave_sync();                                       // scratch is reused by the next sub-block
+        pos += part;
+    }
+    return op;
+}

@@ -1,0 +1,65 @@
+// lz_wave.h — gfx950 wavefront primitives used by the Lizard block kernels.
+//
+// One Lizard API block is parsed by ONE 64-lane wavefront (the LZ77 parse is a serial dependency
+// chain; parallelism inside a block is the 64 speculative probes of one search round, parallelism
+// across blocks is thousands of resident waves).  Everything the kernels need from the machine is
+// named here so the kernel bodies (lz_block.h, lz_huf.h) read as algorithm, and so the test-only SIMT
+// emulator (tests/emul/lz_wave.h) can supply the same names on a CPU to run the very same kernel
+// bodies under pytest -m "not gpu".  This file is the gfx950 one: it is what hipcc sees.
+#ifndef LZ_WAVE_H_
+#define LZ_WAVE_H_   /* shared guard: the first lz_wave.h seen (gfx950 or test emulator) wins */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint8_t  u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define LZ_DEV __device__ __forceinline__
+#define LZ_DEV_NOINLINE __device__ __noinline__
+#define LZ_WAVE 64
+
+// lane index inside the wavefront (workgroups are launched with blockDim.x a multiple of 64)
+LZ_DEV u32 lz_lane() { return threadIdx.x & 63u; }
+
+// 64-bit lane mask of `pred` over the active lanes (wave-uniform result, lives in an SGPR pair)
+LZ_DEV u64 lz_ballot(bool pred) { return __ballot(pred); }
+
+// value of `v` in lane `src` where `src` is wave-uniform: v_readlane_b32, result is scalar
+LZ_DEV u32 lz_readlane(u32 v, u32 src) { return (u32)__builtin_amdgcn_readlane((int)v, (int)src); }
+
+// value held by the first active lane, as a scalar.  Used to pin wave-uniform state into SGPRs.
+LZ_DEV u32 lz_uniform(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+
+// arbitrary cross-lane gather (ds_bpermute_b32): every lane names its own source lane
+LZ_DEV u32 lz_shfl(u32 v, u32 srcLane) { return (u32)__builtin_amdgcn_ds_bpermute((int)(srcLane << 2), (int)v); }
+
+// Ordering point for LDS / global traffic between the lanes of ONE wave: all earlier stores of every
+// lane are visible to later loads of every lane.  Lanes of a wave execute DS/VMEM instructions in
+// program order, so no s_barrier is needed; the fence stops the compiler from forwarding a lane's
+// own store to its later load (or hoisting loads) across the point and drains lgkmcnt/vmcnt.
+LZ_DEV void lz_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+LZ_DEV u32 lz_ctz64(u64 m) { return (u32)__builtin_ctzll(m); }         // m != 0
+LZ_DEV u32 lz_clz64(u64 m) { return (u32)__builtin_clzll(m); }         // m != 0
+LZ_DEV u32 lz_popc64(u64 m) { return (u32)__builtin_popcountll(m); }
+
+// LDS atomic add (histograms)
+LZ_DEV u32 lz_lds_atomic_add(u32* p, u32 v) { return atomicAdd(p, v); }
+
+// Unaligned little-endian loads/stores from global memory.  gfx950 global/flat accesses have no
+// alignment requirement (unaligned access mode), so these compile to single dword/dwordx2 ops.
+struct __attribute__((packed, aligned(1))) lz_u16u { u16 v; };
+struct __attribute__((packed, aligned(1))) lz_u32u { u32 v; };
+struct __attribute__((packed, aligned(1))) lz_u64u { u64 v; };
+LZ_DEV u32 lz_ld32(const u8* p) { return reinterpret_cast<const lz_u32u*>(p)->v; }
+LZ_DEV u64 lz_ld64(const u8* p) { return reinterpret_cast<const lz_u64u*>(p)->v; }
+LZ_DEV void lz_st16(u8* p, u32 v) { reinterpret_cast<lz_u16u*>(p)->v = (u16)v; }
+LZ_DEV void lz_st32(u8* p, u32 v) { reinterpret_cast<lz_u32u*>(p)->v = v; }
+#endif  /* LZ_WAVE_H_ */

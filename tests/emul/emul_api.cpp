@@ -1,0 +1,39 @@
+// tests/emul/emul_api.cpp — TEST INFRASTRUCTURE ONLY: C entry points that run the product's kernel
+// bodies (lizard_amd/csrc/lz_block.h, ...) on the CPU SIMT emulator. Loaded by tests via ctypes.
+#include "lz_wave.h"            // tests/emul/lz_wave.h (emulator) — must come first, see the shared guard
+#include "../../lizard_amd/csrc/lz_block.h"
+
+namespace {
+struct Args { const u8* src; u32 n; u8* dst; u32 level; u32* table; u8* tag; u8* scratch; u32 result; };
+
+template <int HASHLOG, int TAGLOG>
+void entry_fast(void* a)
+{
+    Args* x = (Args*)a;
+    u32 r = lz_compress_block_fast<HASHLOG, TAGLOG>(x->src, x->n, x->dst, x->level, x->table, x->tag, x->scratch);
+    if (lz_lane() == 0) x->result = r;
+}
+}  // namespace
+
+
+
+// Compress one block with the emulated wave. dst must hold Lizard_compressBound(n) bytes.
+// `seed` drives the lane scheduling order (any value must give identical output).
+extern "C" int emul_compress_block(const void* src, int n, void* dst, int level, unsigned seed)
+{
+    Args a;
+    int base = level >= 30 ? level - 20 : level;
+    int hashLog = base == 10 ? 12 : base == 11 ? 18 : 0;
+    if (!hashLog || level >= 30) return -1;
+    a.src = (const u8*)src; a.n = (u32)n; a.dst = (u8*)dst; a.level = (u32)level; a.result = 0;
+    a.table = (u32*)malloc(sizeof(u32) << hashLog);
+    a.tag = (u8*)malloc(4096);
+    a.scratch = (u8*)malloc(LZ_SCRATCH_BYTES);
+    memset(a.table, 0xA5, sizeof(u32) << hashLog);   // garbage: the kernel must initialise its state
+    memset(a.tag, 0x5A, 4096);
+    memset(a.scratch, 0xCC, LZ_SCRATCH_BYTES);
+    if (hashLog == 12) lzemu::run_wave(entry_fast<12, 12>, &a, seed);
+    else               lzemu::run_wave(entry_fast<18, 12>, &a, seed);
+    free(a.table); free(a.tag); free(a.scratch);
+    return (int)a.result;
+}

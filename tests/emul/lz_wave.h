@@ -1,0 +1,114 @@
+// tests/emul/lz_wave.h — TEST INFRASTRUCTURE ONLY: a 64-lane SIMT emulator for x86-64 hosts.
+//
+// It provides the same names as lizard_amd/csrc/lz_wave.h (the gfx950 one) so that the *unmodified*
+// kernel bodies (lz_block.h, lz_huf.h, ...) can be compiled with g++ and executed lane-for-lane on a
+// CPU in `pytest -m "not gpu"`, where there is no GPU.  It is never part of the product library and
+// cannot be reached from it: the product includes lizard_amd/csrc/lz_wave.h, this file is only found
+// through tests/emul's own -I path (see tests/emul/build.py).
+//
+// Model: each lane is a stackful coroutine (hand-rolled x86-64 context switch).  A lane runs until it
+// reaches a cross-lane operation (ballot / readlane / shfl / wave_sync) and parks; when all 64 lanes
+// have parked at the SAME operation the scheduler computes the results and resumes them.  Between
+// two cross-lane operations the lanes run one after another in a pseudo-random order that changes at
+// every phase, so code that silently depends on which lane wins a same-address store, or that reads
+// another lane's store without an lz_wave_sync() in between, produces run-to-run differences and
+// fails the parity tests.  Parking at different operations (divergent control flow around a
+// cross-lane op) aborts.
+#ifndef LZ_WAVE_H_
+#define LZ_WAVE_H_   /* shared guard: the first lz_wave.h seen (gfx950 or test emulator) wins */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef uint8_t  u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define LZ_DEV static inline
+#define LZ_DEV_NOINLINE static __attribute__((noinline))
+#define LZ_WAVE 64
+
+namespace lzemu {
+
+extern "C" void lzemu_ctx_switch(void** save_sp, void* load_sp);
+
+enum Op { OP_NONE = 0, OP_BALLOT, OP_READLANE, OP_UNIFORM, OP_SHFL, OP_SYNC, OP_DONE };
+
+struct Wave {
+    void*  lane_sp[LZ_WAVE];
+    void*  sched_sp;
+    u8*    stacks;
+    int    cur;                 // lane currently running
+    int    op[LZ_WAVE];         // operation each lane is parked at
+    u64    arg0[LZ_WAVE];       // per-lane operands
+    u64    arg1[LZ_WAVE];
+    u64    res[LZ_WAVE];        // per-lane results
+    u32    rng;
+    void (*entry)(void*);
+    void*  entry_arg;
+    u64    n_ops;
+};
+
+extern thread_local Wave* g_wave;
+
+static inline void park(int op)
+{
+    Wave* w = g_wave;
+    int me = w->cur;
+    w->op[me] = op;
+    lzemu_ctx_switch(&w->lane_sp[me], w->sched_sp);
+}
+
+void run_wave(void (*entry)(void*), void* arg, u32 seed);
+
+}  // namespace lzemu
+
+LZ_DEV u32 lz_lane() { return (u32)lzemu::g_wave->cur; }
+
+LZ_DEV u64 lz_ballot(bool pred)
+{
+    lzemu::Wave* w = lzemu::g_wave; int me = w->cur;
+    w->arg0[me] = pred ? 1 : 0;
+    lzemu::park(lzemu::OP_BALLOT);
+    return w->res[me];
+}
+
+LZ_DEV u32 lz_readlane(u32 v, u32 src)
+{
+    lzemu::Wave* w = lzemu::g_wave; int me = w->cur;
+    w->arg0[me] = v; w->arg1[me] = src;
+    lzemu::park(lzemu::OP_READLANE);
+    return (u32)w->res[me];
+}
+
+LZ_DEV u32 lz_uniform(u32 v)
+{
+    lzemu::Wave* w = lzemu::g_wave; int me = w->cur;
+    w->arg0[me] = v;
+    lzemu::park(lzemu::OP_UNIFORM);
+    return (u32)w->res[me];
+}
+
+LZ_DEV u32 lz_shfl(u32 v, u32 srcLane)
+{
+    lzemu::Wave* w = lzemu::g_wave; int me = w->cur;
+    w->arg0[me] = v; w->arg1[me] = srcLane & 63u;
+    lzemu::park(lzemu::OP_SHFL);
+    return (u32)w->res[me];
+}
+
+LZ_DEV void lz_wave_sync() { lzemu::park(lzemu::OP_SYNC); }
+
+LZ_DEV u32 lz_ctz64(u64 m) { return (u32)__builtin_ctzll(m); }
+LZ_DEV u32 lz_clz64(u64 m) { return (u32)__builtin_clzll(m); }
+LZ_DEV u32 lz_popc64(u64 m) { return (u32)__builtin_popcountll(m); }
+
+LZ_DEV u32 lz_lds_atomic_add(u32* p, u32 v) { u32 o = *p; *p = o + v; return o; }
+
+LZ_DEV u32 lz_ld32(const u8* p) { u32 v; memcpy(&v, p, 4); return v; }
+LZ_DEV u64 lz_ld64(const u8* p) { u64 v; memcpy(&v, p, 8); return v; }
+LZ_DEV void lz_st16(u8* p, u32 v) { u16 x = (u16)v; memcpy(p, &x, 2); }
+LZ_DEV void lz_st32(u8* p, u32 v) { memcpy(p, &v, 4); }
+#endif  /* LZ_WAVE_H_ */
