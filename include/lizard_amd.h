@@ -1,0 +1,126 @@
+/*
+ * lizard_amd.h — C ABI of liblizard_amd.so, the MI355X-native Lizard block-compress path.
+ *
+ * Part 1 is the reference's own block-compression ABI (same names, argument meaning and error
+ * behaviour), so that a program written against inikep/lizard's lib/lizard_compress.h links against
+ * this library unchanged.  Each entry cites the reference declaration it replaces.
+ * Part 2 is the batch extension the GPU needs (the reference API is one-block-synchronous; see
+ * SURVEY.md §8b): many independent blocks per call, host- or device-resident.
+ *
+ * Plain C, plain pointers and sizes; no HIP or torch types in any signature (a HIP stream is passed
+ * as an opaque void*).
+ */
+#ifndef LIZARD_AMD_H
+#define LIZARD_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ======================= Part 1: reference block API (lib/lizard_compress.h) ======================= */
+
+#define LIZARD_MIN_CLEVEL      10            /* reference lib/lizard_compress.h:86 */
+#define LIZARD_MAX_CLEVEL      49            /* reference lib/lizard_compress.h:88 */
+#define LIZARD_DEFAULT_CLEVEL  17            /* reference lib/lizard_compress.h:92 */
+#define LIZARD_MAX_INPUT_SIZE  0x7E000000    /* reference lib/lizard_compress.h:121 */
+#define LIZARD_BLOCK_SIZE      (1<<17)       /* reference lib/lizard_compress.h:122 */
+#define LIZARD_COMPRESSBOUND(isize)  ((unsigned)(isize) > (unsigned)LIZARD_MAX_INPUT_SIZE ? 0 : (isize) + 1 + 1 + ((isize/LIZARD_BLOCK_SIZE)+1)*4)   /* :124 */
+
+typedef struct Lizard_stream_s Lizard_stream_t;   /* opaque, reference lib/lizard_compress.h:94 */
+
+/* reference lib/lizard_compress.h:66 / lib/lizard_compress.c:66 */
+int Lizard_versionNumber(void);
+
+/* reference lib/lizard_compress.h:99 / lib/lizard_compress.c:596.
+ * Returns bytes written into dst, 0 on failure (dst too small, level not accelerated, GPU error).
+ * Never writes past dst+maxDstSize, never reads outside src[0..srcSize). */
+int Lizard_compress(const char* src, char* dst, int srcSize, int maxDstSize, int compressionLevel);
+
+/* reference lib/lizard_compress.h:135 / lib/lizard_compress.c:67 */
+int Lizard_compressBound(int inputSize);
+
+/* reference lib/lizard_compress.h:145-147 / lib/lizard_compress.c:311,583.
+ * `state` must be pointer-aligned (misaligned => 0, as the reference) and Lizard_sizeofState(level)
+ * bytes; its content on entry is irrelevant (the reference re-initialises it on every call, and the
+ * match-finder tables of this implementation live in LDS). */
+int Lizard_sizeofState(int compressionLevel);
+int Lizard_compress_extState(void* state, const char* src, char* dst, int srcSize, int maxDstSize, int compressionLevel);
+
+/* reference lib/lizard_compress.h:159-160,166 / lib/lizard_compress.c:392,417,401 */
+Lizard_stream_t* Lizard_createStream(int compressionLevel);
+int              Lizard_freeStream(Lizard_stream_t* streamPtr);
+Lizard_stream_t* Lizard_resetStream(Lizard_stream_t* streamPtr, int compressionLevel);
+
+/* reference lib/lizard_common.h:493-497 / lib/lizard_compress.c:68,612-630 (level-10 aliases) */
+int Lizard_sizeofState_MinLevel(void);
+int Lizard_compress_MinLevel(const char* source, char* dest, int sourceSize, int maxDestSize);
+int Lizard_compress_extState_MinLevel(void* state, const char* source, char* dest, int inputSize, int maxDestSize);
+Lizard_stream_t* Lizard_resetStream_MinLevel(Lizard_stream_t* streamPtr);
+Lizard_stream_t* Lizard_createStream_MinLevel(void);
+
+/* ======================= Part 2: batch extension (ours) ======================= */
+
+/* Error codes returned (negated) by the LizardGPU_* entry points. */
+enum {
+    LIZARDGPU_OK = 0,
+    LIZARDGPU_ERR_NO_DEVICE = 1,     /* no HIP device / HIP runtime failure at init */
+    LIZARDGPU_ERR_LEVEL = 2,         /* level not implemented on the GPU path */
+    LIZARDGPU_ERR_ARG = 3,           /* bad size / stride / null pointer */
+    LIZARDGPU_ERR_HIP = 4,           /* a HIP call failed (see LizardGPU_lastError) */
+    LIZARDGPU_ERR_NOMEM = 5
+};
+
+/* 1 if `compressionLevel` (after the reference's clamp, lib/lizard_compress.c:303-308) runs on the GPU. */
+int LizardGPU_levelSupported(int compressionLevel);
+
+/* Select the HIP device used by this process for subsequent calls (default: current device 0).
+ * One process per GPU is the intended deployment (torch.distributed / RCCL rank = device). */
+int LizardGPU_setDevice(int device);
+
+/* Human-readable text of the last HIP failure on the calling thread's context ("" if none). */
+const char* LizardGPU_lastError(void);
+
+/* Compress nBlocks independent blocks that are already RESIDENT IN DEVICE MEMORY.
+ *   d_src      : device pointer, block i starts at d_src + i*blockSize; every block is blockSize bytes
+ *                except the last, which is lastBlockSize (1..blockSize)
+ *   d_dst      : device pointer, block i's output starts at d_dst + i*dstStride;
+ *                dstStride >= Lizard_compressBound(blockSize)
+ *   d_sizes    : device pointer to nBlocks uint32: compressed size of each block (never 0: with a
+ *                bound-sized slot compression cannot fail, reference lib/lizard_compress.h:104)
+ *   level      : 10..49, must satisfy LizardGPU_levelSupported
+ *   stream     : hipStream_t as void* (NULL = default stream). The call only enqueues work; outputs are
+ *                valid after the stream is synchronised.  One call in flight per process (the per-wave
+ *                scratch arena is shared).
+ * Each block is what Lizard_compress_extState() produces on a zero-initialised state
+ * (reference lib/lizard_compress.c:583 built with -DLIZARD_RESET_MEM). Returns 0 or -LIZARDGPU_ERR_*. */
+int LizardGPU_compressBlocks_device(const void* d_src, size_t nBlocks, size_t blockSize, size_t lastBlockSize,
+                                    void* d_dst, size_t dstStride, uint32_t* d_sizes,
+                                    int level, void* stream);
+
+/* Same for HOST-resident buffers: stages src to the device, runs the kernels, copies sizes and payload
+ * back (dst slot i at dst + i*dstStride, cSizes[i] bytes valid). Synchronous. */
+int LizardGPU_compressBlocks_host(const void* src, size_t nBlocks, size_t blockSize, size_t lastBlockSize,
+                                  void* dst, size_t dstStride, uint32_t* cSizes, int level);
+
+/* Synthetic input, the reference's benchmark generator (programs/datagen.c:153 RDG_genBuffer).
+ * Host: fills buffer[0..size) exactly like RDG_genBuffer(buffer, size, matchProba, litProba, seed).
+ * Device: block b (b < nBlocks, blockSize bytes each, back to back at d_dst) is
+ * RDG_genBuffer(blockSize, matchProba, litProba, seed0 + b); synchronous. */
+void LizardGPU_datagen_host(void* buffer, size_t size, double matchProba, double litProba, unsigned seed);
+int  LizardGPU_datagen_device(void* d_dst, size_t nBlocks, size_t blockSize, double matchProba, double litProba,
+                              unsigned seed0, void* stream);
+
+/* Kernel-only duration of the most recent LizardGPU_compressBlocks_* call measured with HIP events on
+ * the launch stream, in milliseconds (blocks until that launch finished). < 0 if unavailable. */
+float LizardGPU_lastKernelMs(void);
+
+/* Number of resident waves (= blocks compressed concurrently) the launcher uses on this device. */
+int LizardGPU_residentWaves(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIZARD_AMD_H */

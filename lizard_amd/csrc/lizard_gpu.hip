@@ -1,0 +1,286 @@
+// lizard_gpu.hip — gfx950 kernels + the thin extern "C" shim the host C layer (lizard_host.c) calls.
+//
+// Launch geometry: ONE wavefront (64-thread workgroup) per Lizard API block; the grid is persistent
+// (CUs x resident-workgroups-per-CU) and pulls block indices from a device counter, so a launch over
+// 65 536 blocks keeps every CU's LDS full of match-finder tables (level 10: 16 KiB table + 4 KiB tag
+// per wave -> 8 waves per CU under the 160 KiB LDS) and tail blocks do not strand CUs.  Each wave owns
+// a stream-staging slot in a global scratch arena (L2/MALL resident: written and re-read once per
+// sub-block).  Blocks never communicate, so there is no inter-workgroup synchronisation at all.
+#include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/lizard_amd.h"
+#include "lz_block.h"
+#include "lz_datagen.h"
+
+namespace {
+
+struct LzBatch {
+    const u8* src;  u64 blockSize;  u32 nBlocks;  u32 lastBlockSize;
+    u8* dst;        u64 dstStride;  u32* sizes;   u32 level;
+    u8* scratch;    u32* counter;
+};
+
+// level 10/30 parser: hash table (2^12 x u32) and the round tag array (2^12 x u8) live in LDS.
+__global__ __launch_bounds__(64) void lz_fast12_kernel(LzBatch a)
+{
+    __shared__ u32 table[1u << 12];
+    __shared__ u8  tag[1u << 12];
+    u8* scratch = a.scratch + (u64)blockIdx.x * LZ_SCRATCH_BYTES;
+    for (;;) {
+        u32 b = 0;
+        if (lz_lane() == 0) b = atomicAdd(a.counter, 1u);
+        b = lz_uniform(b);
+        if (b >= a.nBlocks) break;
+        const u32 n = (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
+        const u32 c = lz_compress_block_fast<12, 12>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
+                                                     a.level, table, tag, scratch);
+        if (lz_lane() == 0) a.sizes[b] = c;
+    }
+}
+
+// synthetic input: one thread per block, block b = RDG_genBuffer(blockSize, P, seed0 + b)
+__global__ __launch_bounds__(64) void lz_datagen_kernel(u8* dst, u64 nBlocks, u64 blockSize, u32 matchProba32,
+                                                        int zeroRuns, const u8* lt, u32 seed0)
+{
+    const u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nBlocks) lz_rdg_fill(dst + b * blockSize, (size_t)blockSize, matchProba32, zeroRuns, lt, seed0 + (u32)b);
+}
+
+// ------------------------------------------------------------------------------------------------
+struct Ctx {
+    int   device = -1;
+    int   cus = 0;
+    int   waves = 0;            // persistent grid size
+    u8*   scratch = nullptr;
+    u32*  counter = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool  timed = false;
+    // host-path staging
+    u8*   d_src = nullptr;  size_t d_src_cap = 0;
+    u8*   d_dst = nullptr;  size_t d_dst_cap = 0;
+    u32*  d_sizes = nullptr; size_t d_sizes_cap = 0;
+    hipStream_t stream = nullptr;
+    char  err[256] = {0};
+};
+
+Ctx g_ctx;
+int g_want_device = 0;
+pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
+
+#define LZ_HIP(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            snprintf(g_ctx.err, sizeof g_ctx.err, "%s failed: %s", #call, hipGetErrorString(e_));      \
+            return -LIZARDGPU_ERR_HIP;                                                                 \
+        }                                                                                              \
+    } while (0)
+
+int ctx_init_locked()
+{
+    if (g_ctx.device == g_want_device && g_ctx.scratch) return 0;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        snprintf(g_ctx.err, sizeof g_ctx.err, "no HIP device visible");
+        return -LIZARDGPU_ERR_NO_DEVICE;
+    }
+    LZ_HIP(hipSetDevice(g_want_device));
+    hipDeviceProp_t prop;
+    LZ_HIP(hipGetDeviceProperties(&prop, g_want_device));
+    int perCu = 0;
+    LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, lz_fast12_kernel, 64, 0));
+    if (perCu < 1) perCu = 1;
+    g_ctx.cus = prop.multiProcessorCount;
+    g_ctx.waves = g_ctx.cus * perCu;
+    LZ_HIP(hipMalloc((void**)&g_ctx.scratch, (size_t)g_ctx.waves * LZ_SCRATCH_BYTES));
+    LZ_HIP(hipMalloc((void**)&g_ctx.counter, 64));
+    LZ_HIP(hipEventCreate(&g_ctx.ev0));
+    LZ_HIP(hipEventCreate(&g_ctx.ev1));
+    LZ_HIP(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+    g_ctx.device = g_want_device;
+    return 0;
+}
+
+int launch_locked(const void* d_src, size_t nBlocks, size_t blockSize, size_t lastBlockSize, void* d_dst,
+                  size_t dstStride, u32* d_sizes, int level, hipStream_t stream)
+{
+    if (!LizardGPU_levelSupported(level)) return -LIZARDGPU_ERR_LEVEL;
+    if (!d_src || !d_dst || !d_sizes || nBlocks == 0 || nBlocks > 0xFFFFFFFFu) return -LIZARDGPU_ERR_ARG;
+    if (blockSize == 0 || blockSize > LIZARD_MAX_INPUT_SIZE || lastBlockSize == 0 || lastBlockSize > blockSize) return -LIZARDGPU_ERR_ARG;
+    if (dstStride < (size_t)LIZARD_COMPRESSBOUND((int)blockSize)) return -LIZARDGPU_ERR_ARG;
+    int rc = ctx_init_locked();
+    if (rc) return rc;
+    LzBatch a;
+    a.src = (const u8*)d_src; a.blockSize = blockSize; a.nBlocks = (u32)nBlocks; a.lastBlockSize = (u32)lastBlockSize;
+    a.dst = (u8*)d_dst; a.dstStride = dstStride; a.sizes = d_sizes; a.level = (u32)level;
+    a.scratch = g_ctx.scratch; a.counter = g_ctx.counter;
+    const u32 grid = (u32)(nBlocks < (size_t)g_ctx.waves ? nBlocks : (size_t)g_ctx.waves);
+    LZ_HIP(hipMemsetAsync(g_ctx.counter, 0, 4, stream));
+    LZ_HIP(hipEventRecord(g_ctx.ev0, stream));
+    hipLaunchKernelGGL(lz_fast12_kernel, dim3(grid), dim3(64), 0, stream, a);
+    LZ_HIP(hipGetLastError());
+    LZ_HIP(hipEventRecord(g_ctx.ev1, stream));
+    g_ctx.timed = true;
+    return 0;
+}
+
+template <typename T>
+int ensure(T** p, size_t* cap, size_t need)
+{
+    if (*cap >= need) return 0;
+    if (*p) { LZ_HIP(hipFree(*p)); *p = nullptr; *cap = 0; }
+    LZ_HIP(hipMalloc((void**)p, need));
+    *cap = need;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int LizardGPU_levelSupported(int level)
+{
+    if (level > LIZARD_MAX_CLEVEL) level = LIZARD_MAX_CLEVEL;        // reference lizard_compress.c:303-308
+    if (level < LIZARD_MIN_CLEVEL) level = LIZARD_DEFAULT_CLEVEL;
+    return level == 10;
+}
+
+int LizardGPU_setDevice(int device)
+{
+    pthread_mutex_lock(&g_mu);
+    g_want_device = device;
+    pthread_mutex_unlock(&g_mu);
+    return 0;
+}
+
+const char* LizardGPU_lastError(void) { return g_ctx.err; }
+
+int LizardGPU_residentWaves(void)
+{
+    pthread_mutex_lock(&g_mu);
+    int rc = ctx_init_locked();
+    int w = rc ? rc : g_ctx.waves;
+    pthread_mutex_unlock(&g_mu);
+    return w;
+}
+
+int LizardGPU_compressBlocks_device(const void* d_src, size_t nBlocks, size_t blockSize, size_t lastBlockSize,
+                                    void* d_dst, size_t dstStride, uint32_t* d_sizes, int level, void* stream)
+{
+    pthread_mutex_lock(&g_mu);
+    int rc = launch_locked(d_src, nBlocks, blockSize, lastBlockSize, d_dst, dstStride, d_sizes, level, (hipStream_t)stream);
+    pthread_mutex_unlock(&g_mu);
+    return rc;
+}
+
+static int host_locked(const void* src, size_t nBlocks, size_t blockSize, size_t lastBlockSize, void* dst,
+                       size_t dstStride, uint32_t* cSizes, int level)
+{
+    if (!src || !dst || !cSizes || nBlocks == 0 || blockSize == 0 || lastBlockSize == 0 || lastBlockSize > blockSize)
+        return -LIZARDGPU_ERR_ARG;
+    int rc = ctx_init_locked();
+    if (rc) return rc;
+    const size_t srcBytes = (nBlocks - 1) * blockSize + lastBlockSize;
+    const size_t slot = ((size_t)LIZARD_COMPRESSBOUND((int)blockSize) + 63) & ~(size_t)63;
+    if (dstStride < (size_t)LIZARD_COMPRESSBOUND((int)blockSize)) return -LIZARDGPU_ERR_ARG;
+    if ((rc = ensure(&g_ctx.d_src, &g_ctx.d_src_cap, srcBytes + 64))) return rc;
+    if ((rc = ensure(&g_ctx.d_dst, &g_ctx.d_dst_cap, nBlocks * slot))) return rc;
+    if ((rc = ensure(&g_ctx.d_sizes, &g_ctx.d_sizes_cap, nBlocks * sizeof(u32)))) return rc;
+    hipStream_t s = g_ctx.stream;
+    LZ_HIP(hipMemcpyAsync(g_ctx.d_src, src, srcBytes, hipMemcpyHostToDevice, s));
+    rc = launch_locked(g_ctx.d_src, nBlocks, blockSize, lastBlockSize, g_ctx.d_dst, slot, g_ctx.d_sizes, level, s);
+    if (rc) return rc;
+    LZ_HIP(hipMemcpyAsync(cSizes, g_ctx.d_sizes, nBlocks * sizeof(u32), hipMemcpyDeviceToHost, s));
+    LZ_HIP(hipStreamSynchronize(s));
+    // payload: only the valid bytes of each slot travel back
+    for (size_t i = 0; i < nBlocks; i++)
+        LZ_HIP(hipMemcpyAsync((u8*)dst + i * dstStride, g_ctx.d_dst + i * slot, cSizes[i], hipMemcpyDeviceToHost, s));
+    LZ_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+int LizardGPU_compressBlocks_host(const void* src, size_t nBlocks, size_t blockSize, size_t lastBlockSize,
+                                  void* dst, size_t dstStride, uint32_t* cSizes, int level)
+{
+    pthread_mutex_lock(&g_mu);
+    int rc = host_locked(src, nBlocks, blockSize, lastBlockSize, dst, dstStride, cSizes, level);
+    pthread_mutex_unlock(&g_mu);
+    return rc;
+}
+
+// Internal shim for the one-block reference entry points (lizard_host.c): compress one host block,
+// honouring the reference's maxDstSize contract: returns the compressed size, 0 if it does not fit
+// (reference lib/lizard_compress.c:543-546), < 0 on a GPU failure.
+int lzgpu_compress_one(const void* src, int srcSize, void* dst, int maxDstSize, int level)
+{
+    if (srcSize < 0 || (unsigned)srcSize > (unsigned)LIZARD_MAX_INPUT_SIZE || maxDstSize < 1) return 0;
+    pthread_mutex_lock(&g_mu);
+    int rc = ctx_init_locked();
+    int result = 0;
+    if (!rc && srcSize == 0) {          // reference: level byte only (lizard_compress.c:488-494)
+        ((u8*)dst)[0] = (u8)level; result = 1;
+    } else if (!rc) {
+        const size_t slot = (size_t)LIZARD_COMPRESSBOUND(srcSize);
+        u32 csize = 0;
+        do {
+            if ((rc = ensure(&g_ctx.d_src, &g_ctx.d_src_cap, (size_t)srcSize + 64))) break;
+            if ((rc = ensure(&g_ctx.d_dst, &g_ctx.d_dst_cap, slot))) break;
+            if ((rc = ensure(&g_ctx.d_sizes, &g_ctx.d_sizes_cap, sizeof(u32)))) break;
+            hipStream_t s = g_ctx.stream;
+            if (hipMemcpyAsync(g_ctx.d_src, src, (size_t)srcSize, hipMemcpyHostToDevice, s) != hipSuccess) { rc = -LIZARDGPU_ERR_HIP; break; }
+            if ((rc = launch_locked(g_ctx.d_src, 1, (size_t)srcSize, (size_t)srcSize, g_ctx.d_dst, slot, g_ctx.d_sizes, level, s))) break;
+            if (hipMemcpyAsync(&csize, g_ctx.d_sizes, sizeof(u32), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = -LIZARDGPU_ERR_HIP; break; }
+            if (hipStreamSynchronize(s) != hipSuccess) { rc = -LIZARDGPU_ERR_HIP; break; }
+            if (csize > (u32)maxDstSize) { result = 0; break; }
+            if (hipMemcpy(dst, g_ctx.d_dst, csize, hipMemcpyDeviceToHost) != hipSuccess) { rc = -LIZARDGPU_ERR_HIP; break; }
+            result = (int)csize;
+        } while (0);
+    }
+    pthread_mutex_unlock(&g_mu);
+    return rc ? rc : result;
+}
+
+void LizardGPU_datagen_host(void* buffer, size_t size, double matchProba, double litProba, unsigned seed)
+{
+    uint8_t lt[LZ_RDG_LTSIZE];
+    lz_rdg_table(lt, matchProba, litProba);
+    lz_rdg_fill((uint8_t*)buffer, size, (uint32_t)(32768 * matchProba), matchProba >= 1.0, lt, seed);
+}
+
+int LizardGPU_datagen_device(void* d_dst, size_t nBlocks, size_t blockSize, double matchProba, double litProba,
+                             unsigned seed0, void* stream)
+{
+    if (!d_dst || nBlocks == 0 || blockSize == 0) return -LIZARDGPU_ERR_ARG;
+    pthread_mutex_lock(&g_mu);
+    int rc = ctx_init_locked();
+    if (!rc) do {
+        uint8_t lt[LZ_RDG_LTSIZE];
+        lz_rdg_table(lt, matchProba, litProba);
+        u8* d_lt = nullptr;
+        if (hipMalloc((void**)&d_lt, LZ_RDG_LTSIZE) != hipSuccess) { rc = -LIZARDGPU_ERR_NOMEM; break; }
+        hipStream_t s = (hipStream_t)stream;
+        if (hipMemcpyAsync(d_lt, lt, LZ_RDG_LTSIZE, hipMemcpyHostToDevice, s) != hipSuccess) { rc = -LIZARDGPU_ERR_HIP; (void)hipFree(d_lt); break; }
+        hipLaunchKernelGGL(lz_datagen_kernel, dim3((unsigned)((nBlocks + 63) / 64)), dim3(64), 0, s, (u8*)d_dst, (u64)nBlocks,
+                           (u64)blockSize, (u32)(32768 * matchProba), (int)(matchProba >= 1.0), (const u8*)d_lt, (u32)seed0);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = -LIZARDGPU_ERR_HIP;
+        (void)hipFree(d_lt);
+    } while (0);
+    pthread_mutex_unlock(&g_mu);
+    return rc;
+}
+
+float LizardGPU_lastKernelMs(void)
+{
+    float ms = -1.0f;
+    pthread_mutex_lock(&g_mu);
+    if (g_ctx.timed && hipEventSynchronize(g_ctx.ev1) == hipSuccess) {
+        if (hipEventElapsedTime(&ms, g_ctx.ev0, g_ctx.ev1) != hipSuccess) ms = -1.0f;
+    }
+    pthread_mutex_unlock(&g_mu);
+    return ms;
+}
+
+}  // extern "C"

@@ -57,6 +57,7 @@ int lzo_level_supported(int level)
 {
     lzo_params p;
     if (level < 10 || level > 49) return 0;
+    if (level >= 30 && lzo_huf_compress(NULL, 0, NULL, 0) == (size_t)-2) return 0;   /* huff0 stage not restated yet */
     return lzo_get_params(level, &p);
 }
 

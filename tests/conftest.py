@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _have_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)

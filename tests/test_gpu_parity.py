@@ -1,0 +1,141 @@
+"""GPU (-m gpu): parity of the HIP path, called through the C ABI (liblizard_amd.so), against
+ * the oracle restatement (oracle/liblizard_oracle.so) on the same seeded inputs,
+ * the golden vectors recorded from the compiled reference (tests/golden/reference_vectors.json),
+ * the prebuilt reference library oracle/_ref/*.so when it travelled to this box,
+ * and, at BASELINE.json sizes, size-independent properties (known-answer chained XXH64 over 64 MiB of
+   datagen P50; reference decoder round trip; run-to-run determinism).
+Bit-exact is the bar: this is integer/byte work."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import xxhash
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+with open(os.path.join(util.GOLDEN_DIR, "reference_vectors.json")) as f:
+    GOLDEN = json.load(f)
+
+
+@pytest.fixture(scope="module")
+def L():
+    from lizard_amd import _lib
+    return _lib.lib()      # raises loudly if the HIP extension is not built
+
+
+def gpu_levels(L):
+    return [l for l in GOLDEN["levels"] if L.LizardGPU_levelSupported(l)]
+
+
+def gpu_compress(L, data, level, cap=None):
+    return util.compress_with(L.Lizard_compress, data, level, cap)
+
+
+def test_library_loaded_is_in_tree(L):
+    from lizard_amd import _lib
+    assert os.path.samefile(os.path.dirname(_lib.LIB_PATH), os.path.join(util.ROOT, "lizard_amd"))
+    assert L.LizardGPU_residentWaves() >= 256
+
+
+def test_corpus_vs_golden_and_oracle(L):
+    """Every corpus case (empty, ragged, degenerate, incompressible...) one block per call."""
+    levels = gpu_levels(L)
+    assert 10 in levels
+    for level in levels:
+        for name, data in util.corpus():
+            out, r = gpu_compress(L, data, level)
+            g = GOLDEN["cases"][name]["out"][str(level)]
+            assert r == g["size"], (name, level, r, g["size"])
+            assert util.sha(out) == g["sha256"], (name, level)
+            assert out == util.oracle_compress(data, level), (name, level)
+
+
+def test_frame_style_capacity(L):
+    """maxDstSize = srcSize-1 (reference lib/lizard_frame.c:461): identical bytes when it fits, 0 when not."""
+    for level in [l for l in (10, 21, 30) if L.LizardGPU_levelSupported(l)]:
+        for name, data in util.corpus(small=True):
+            if len(data) < 2:
+                continue
+            out, r = gpu_compress(L, data, level, cap=len(data) - 1)
+            g = GOLDEN["frame_style"][name][str(level)]
+            assert r == g["size"] and util.sha(out) == g["sha256"], (name, level)
+    data = dict(util.corpus(small=True))["gen65537_p0.5"]
+    exact = len(util.oracle_compress(data, 10))
+    for cap in (1, 2, exact - 1, exact, exact + 1):
+        out, r = gpu_compress(L, data, 10, cap=cap)
+        want, rw = util.compress_with(util.oracle().lzo_compress, data, 10, cap=cap)
+        assert r == rw and out == want[:r], cap
+        assert r <= cap
+
+
+def test_batch_host_ragged(L):
+    """Batched host entry: many blocks, ragged last block, several block sizes."""
+    from lizard_amd import api
+    data = util.datagen(3 * 262144 + 12345, 0.5, 0.0, 77) + bytes(70000) + util.datagen(200000, 0.1, 0.0, 5)
+    for level in gpu_levels(L):
+        for bs in (4096, 65536, 131072, 262144, 1 << 20):
+            outs = api.compress_blocks(data, bs, level)
+            assert len(outs) == (len(data) + bs - 1) // bs
+            for i, o in enumerate(outs):
+                assert o == util.oracle_compress(data[i * bs:(i + 1) * bs], level), (level, bs, i)
+
+
+@pytest.mark.parametrize("key", sorted(k for k in GOLDEN["p50_64m"] if k.startswith("L")))
+def test_known_answers_p50_64m_device_path(L, key):
+    """SURVEY.md §8c known answers through the device-resident batch entry (bench.py's path)."""
+    import torch
+    from lizard_amd import api
+    level, bs = int(key[1:].split("_B")[0]), int(key.split("_B")[1])
+    if not L.LizardGPU_levelSupported(level):
+        pytest.skip("level not on the GPU path yet")
+    N = 64 << 20
+    host = np.frombuffer(util.datagen(N, 0.5, 0.0, 0), dtype=np.uint8)
+    src = torch.from_numpy(host.copy()).cuda()
+    dst, sizes, stride = api.compress_blocks_device(src, bs, level)
+    torch.cuda.synchronize()
+    sz = sizes.cpu().numpy().astype(np.int64)
+    out = dst.cpu().numpy()
+    assert int(sz.sum()) == GOLDEN["p50_64m"][key]["sum"]
+    assert list(sz[:8]) == GOLDEN["p50_64m"][key]["first_sizes"]
+    h = 0
+    for i in range(N // bs):
+        h = xxhash.xxh64(out[i * stride:i * stride + sz[i]].tobytes(), seed=h).intdigest()
+    assert "%016x" % h == GOLDEN["p50_64m"][key]["xxh64_chain"]
+    # determinism: a second launch produces the same bytes
+    dst2, sizes2, _ = api.compress_blocks_device(src, bs, level)
+    torch.cuda.synchronize()
+    assert torch.equal(sizes, sizes2)
+    sel = torch.arange(stride, device="cuda")[None, :] < sizes[:, None]
+    assert torch.equal(dst.view(-1, stride)[sel], dst2.view(-1, stride)[sel])
+
+
+def test_roundtrip_with_reference_decoder(L):
+    """Full-size property: what the GPU writes decodes with the unmodified reference decoder."""
+    ref = util.reference()
+    if ref is None:
+        pytest.skip("oracle/_ref not present on this box")
+    from lizard_amd import api
+    data = util.datagen(16 << 20, 0.5, 0.0, 3) + os.urandom(1 << 20) + bytes(1 << 20)
+    for level in gpu_levels(L):
+        bs = 262144
+        outs = api.compress_blocks(data, bs, level)
+        back = ctypes.create_string_buffer(bs)
+        for i, o in enumerate(outs):
+            n = ref.Lizard_decompress_safe(o, back, len(o), bs)
+            assert n == len(data[i * bs:(i + 1) * bs]) and back.raw[:n] == data[i * bs:(i + 1) * bs], (level, i)
+
+
+def test_device_datagen_matches_host(L):
+    """bench.py's on-device input generator == the host generator == reference RDG_genBuffer."""
+    import torch
+    for bs, nb, p in [(262144, 70, 0.5), (4096, 300, 0.2), (65536, 65, 1.0), (1000, 64, 0.0)]:
+        d = torch.empty(nb * bs, dtype=torch.uint8, device="cuda")
+        rc = L.LizardGPU_datagen_device(d.data_ptr(), nb, bs, p, 0.0, 1000, None)
+        assert rc == 0
+        got = d.cpu().numpy().tobytes()
+        for b in (0, 1, nb // 2, nb - 1):
+            assert got[b * bs:(b + 1) * bs] == util.datagen(bs, p, 0.0, 1000 + b), (bs, b, p)

@@ -1,0 +1,143 @@
+"""Shared test helpers: loading the checker libraries (oracle restatement, compiled reference when
+present, SIMT emulator) and the deterministic input corpus.  Everything here is test infrastructure."""
+import ctypes
+import hashlib
+import os
+import random
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+REF_DIR = os.path.join(ORACLE_DIR, "_ref")
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+_c = ctypes
+_COMPRESS_SIG = [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int]
+
+
+def build_oracle():
+    """(Re)build oracle/liblizard_oracle.so (and oracle/_ref when /root/reference is present)."""
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "all"])
+
+
+_oracle = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        path = os.path.join(ORACLE_DIR, "liblizard_oracle.so")
+        srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+        if not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
+            build_oracle()
+        L = ctypes.CDLL(path)
+        L.lzo_compress.argtypes = _COMPRESS_SIG; L.lzo_compress.restype = _c.c_int
+        L.lzo_compress_bound.argtypes = [_c.c_int]; L.lzo_compress_bound.restype = _c.c_int
+        L.lzo_level_supported.argtypes = [_c.c_int]
+        L.lzo_datagen.argtypes = [_c.c_void_p, _c.c_size_t, _c.c_double, _c.c_double, _c.c_uint]
+        L.lzo_huf_compress.argtypes = [_c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t]; L.lzo_huf_compress.restype = _c.c_size_t
+        _oracle = L
+    return _oracle
+
+
+_ref = None
+
+
+def reference():
+    """The unmodified reference built with -DLIZARD_RESET_MEM (zero-state oracle), or None."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(REF_DIR, "liblizard_ref_reset.so")
+        if not os.path.exists(path):
+            if os.path.exists("/root/reference/lib/lizard_compress.c"):
+                build_oracle()
+            else:
+                return None
+        L = ctypes.CDLL(path)
+        L.Lizard_compress.argtypes = _COMPRESS_SIG; L.Lizard_compress.restype = _c.c_int
+        L.Lizard_compressBound.argtypes = [_c.c_int]
+        L.Lizard_decompress_safe.argtypes = [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int]; L.Lizard_decompress_safe.restype = _c.c_int
+        L.HUF_compress.argtypes = [_c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t]; L.HUF_compress.restype = _c.c_size_t
+        _ref = L
+    return _ref
+
+
+def reference_datagen():
+    path = os.path.join(REF_DIR, "libdatagen_ref.so")
+    if not os.path.exists(path):
+        return None
+    L = ctypes.CDLL(path)
+    L.RDG_genBuffer.argtypes = [_c.c_void_p, _c.c_size_t, _c.c_double, _c.c_double, _c.c_uint]
+    return L
+
+
+_emul = None
+
+
+def emulator():
+    global _emul
+    if _emul is None:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("emul_build", os.path.join(ROOT, "tests", "emul", "build.py"))
+        mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+        L = ctypes.CDLL(mod.build())
+        L.emul_compress_block.argtypes = [_c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int, _c.c_uint]
+        L.emul_compress_block.restype = _c.c_int
+        _emul = L
+    return _emul
+
+
+def compress_with(fn, data, level, cap=None):
+    """Run a (src, dst, n, cap, level) -> size C compressor over `data`; returns the output bytes."""
+    n = len(data)
+    bound = oracle().lzo_compress_bound(n)
+    cap = bound if cap is None else cap
+    dst = ctypes.create_string_buffer(max(cap, 1) + 64)
+    src = ctypes.create_string_buffer(bytes(data), n) if n else ctypes.create_string_buffer(1)
+    r = fn(src, dst, n, cap, level)
+    return dst.raw[:max(r, 0)], r
+
+
+def oracle_compress(data, level, cap=None):
+    return compress_with(oracle().lzo_compress, data, level, cap)[0]
+
+
+def datagen(size, match_proba=0.5, lit_proba=0.0, seed=0):
+    buf = ctypes.create_string_buffer(max(size, 1))
+    oracle().lzo_datagen(buf, size, match_proba, lit_proba, seed)
+    return buf.raw[:size]
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+EDGE_SIZES = [0, 1, 5, 16, 19, 20, 21, 22, 23, 40, 63, 64, 65, 100, 1000, 4096, 65535, 65536, 65537, 131071, 131072,
+              131073, 131072 + 20, 131072 + 21, 131072 + 22, 200000, 262144, 300000]
+
+
+def corpus(small=False):
+    """Deterministic named inputs: datagen at several compressibilities and ragged sizes, degenerate
+    periodic data (exercise same-hash lanes inside one round), incompressible noise (exercise the
+    skip schedule and the stored-raw fallback)."""
+    rnd = random.Random(1234)
+    out = []
+    sizes = [0, 1, 20, 21, 22, 65, 1000, 65537, 131072, 131073, 131072 + 21, 262144] if small else EDGE_SIZES
+    for size in sizes:
+        for p in ([0.5] if small else [0.0, 0.2, 0.5, 0.9, 1.0]):
+            out.append((f"gen{size}_p{p}", datagen(size, p, 0.0, size + 7)))
+    n = 262144
+    out += [
+        ("zeros300k", bytes(300000)),
+        ("ff256k", b"\xff" * n),
+        ("period3", (b"abc" * (n // 3 + 1))[:n]),
+        ("period8", (b"abcdefgh" * (n // 8))[:n]),
+        ("period9", (b"abcdefghi" * (n // 9 + 1))[:n]),
+        ("period64", (bytes(range(64)) * (n // 64))[:n]),
+        ("period65", (bytes(range(65)) * (n // 65 + 1))[:n]),
+        ("random256k", rnd.randbytes(n)),
+        ("alpha2", bytes(rnd.choice(b"ab") for _ in range(200000))),
+        ("alpha4", bytes(rnd.choice(b"abcd") for _ in range(200000))),
+        ("text", (b"the quick brown fox jumps over the lazy dog. " * 6000)[:n]),
+    ]
+    return out
