@@ -23,11 +23,14 @@ struct LzBatch {
     u8* scratch;    u32* counter;
 };
 
-// level 10/30 parser: hash table (2^12 x u32) and the round tag array (2^12 x u8) live in LDS.
+// level 10/30 parser: hash table (2^12 x u32) and the round tag array (2^12 x u8) live in LDS; at
+// level 30 the tag array doubles as the Huffman stage's workspace (the two are never live together).
+template <bool HUF>
 __global__ __launch_bounds__(64) void lz_fast12_kernel(LzBatch a)
 {
     __shared__ u32 table[1u << 12];
-    __shared__ u8  tag[1u << 12];
+    __shared__ u32 tagws[HUF ? LZ_HUF_WS_WORDS : 1024u];
+    u8* tag = (u8*)tagws;
     u8* scratch = a.scratch + (u64)blockIdx.x * LZ_SCRATCH_BYTES;
     for (;;) {
         u32 b = 0;
@@ -35,7 +38,7 @@ __global__ __launch_bounds__(64) void lz_fast12_kernel(LzBatch a)
         b = lz_uniform(b);
         if (b >= a.nBlocks) break;
         const u32 n = (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
-        const u32 c = lz_compress_block_fast<12, 12>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
+        const u32 c = lz_compress_block_fast<12, 12, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
                                                      a.level, table, tag, scratch);
         if (lz_lane() == 0) a.sizes[b] = c;
     }
@@ -53,7 +56,8 @@ __global__ __launch_bounds__(64) void lz_datagen_kernel(u8* dst, u64 nBlocks, u6
 struct Ctx {
     int   device = -1;
     int   cus = 0;
-    int   waves = 0;            // persistent grid size
+    int   waves = 0;            // persistent grid size (level 10)
+    int   wavesHuf = 0;         // persistent grid size (level 30: larger LDS workspace)
     u8*   scratch = nullptr;
     u32*  counter = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -90,11 +94,14 @@ int ctx_init_locked()
     LZ_HIP(hipSetDevice(g_want_device));
     hipDeviceProp_t prop;
     LZ_HIP(hipGetDeviceProperties(&prop, g_want_device));
-    int perCu = 0;
-    LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, lz_fast12_kernel, 64, 0));
+    int perCu = 0, perCuHuf = 0;
+    LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, lz_fast12_kernel<false>, 64, 0));
+    LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuHuf, lz_fast12_kernel<true>, 64, 0));
     if (perCu < 1) perCu = 1;
+    if (perCuHuf < 1) perCuHuf = 1;
     g_ctx.cus = prop.multiProcessorCount;
     g_ctx.waves = g_ctx.cus * perCu;
+    g_ctx.wavesHuf = g_ctx.cus * perCuHuf;
     LZ_HIP(hipMalloc((void**)&g_ctx.scratch, (size_t)g_ctx.waves * LZ_SCRATCH_BYTES));
     LZ_HIP(hipMalloc((void**)&g_ctx.counter, 64));
     LZ_HIP(hipEventCreate(&g_ctx.ev0));
@@ -117,10 +124,15 @@ int launch_locked(const void* d_src, size_t nBlocks, size_t blockSize, size_t la
     a.src = (const u8*)d_src; a.blockSize = blockSize; a.nBlocks = (u32)nBlocks; a.lastBlockSize = (u32)lastBlockSize;
     a.dst = (u8*)d_dst; a.dstStride = dstStride; a.sizes = d_sizes; a.level = (u32)level;
     a.scratch = g_ctx.scratch; a.counter = g_ctx.counter;
-    const u32 grid = (u32)(nBlocks < (size_t)g_ctx.waves ? nBlocks : (size_t)g_ctx.waves);
+    int lv = level > LIZARD_MAX_CLEVEL ? LIZARD_MAX_CLEVEL : level;
+    if (lv < LIZARD_MIN_CLEVEL) lv = LIZARD_DEFAULT_CLEVEL;
+    a.level = (u32)lv;
+    const size_t resident = (size_t)(lv >= 30 ? g_ctx.wavesHuf : g_ctx.waves);
+    const u32 grid = (u32)(nBlocks < resident ? nBlocks : resident);
     LZ_HIP(hipMemsetAsync(g_ctx.counter, 0, 4, stream));
     LZ_HIP(hipEventRecord(g_ctx.ev0, stream));
-    hipLaunchKernelGGL(lz_fast12_kernel, dim3(grid), dim3(64), 0, stream, a);
+    if (lv == 30) hipLaunchKernelGGL(lz_fast12_kernel<true>, dim3(grid), dim3(64), 0, stream, a);
+    else          hipLaunchKernelGGL(lz_fast12_kernel<false>, dim3(grid), dim3(64), 0, stream, a);
     LZ_HIP(hipGetLastError());
     LZ_HIP(hipEventRecord(g_ctx.ev1, stream));
     g_ctx.timed = true;
@@ -145,7 +157,7 @@ int LizardGPU_levelSupported(int level)
 {
     if (level > LIZARD_MAX_CLEVEL) level = LIZARD_MAX_CLEVEL;        // reference lizard_compress.c:303-308
     if (level < LIZARD_MIN_CLEVEL) level = LIZARD_DEFAULT_CLEVEL;
-    return level == 10;
+    return level == 10 || level == 30;
 }
 
 int LizardGPU_setDevice(int device)

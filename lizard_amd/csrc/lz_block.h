@@ -29,6 +29,7 @@
 // in every lane (they are derived from ballots/readlanes and live in SGPRs).
 #pragma once
 #include "lz_wave.h"
+#include "lz_huf.h"
 
 #define LZ_SUBBLOCK       (1u << 17)        // LIZARD_BLOCK_SIZE, reference lib/lizard_compress.h:122
 #define LZ_SUBBLOCK_PAD   (LZ_SUBBLOCK + 32)
@@ -278,9 +279,41 @@ LZ_DEV u32 lz_write_subblock_raw_streams(const u8* in, u32 n, u8* op, LzStreams&
     return total;
 }
 
+// Lizard_writeBlock with the Huffman stage (levels >= 30): huffType = LITERALS + FLAGS
+// (lizard_compress.c:374-377); off16/off24/len streams are always stored raw.  ws = LDS workspace of
+// LZ_HUF_WS_WORDS words (aliases the parser's tag array, which is idle here).
+LZ_DEV u32 lz_write_subblock_huf(const u8* in, u32 n, u8* op, LzStreams& st, u32* ws)
+{
+    const u32 sum = st.nflags + st.nlit + st.noff16 + st.noff24;
+    bool raw = st.nlit < LZ_LASTLITERALS || sum + 16u > n;             // lizard_compress.c:201
+    u32 total = 0;
+    if (!raw) {
+        lz_wave_sync();
+        u32 hf = 0, hl = 0;
+        u8* q = op + 1;
+        if (lz_lane() == 0) lz_st24(q, 0);                             // empty `len` stream
+        q += 3;
+        q += lz_put_stream_raw(q, st.off16, st.noff16);
+        q += lz_put_stream_raw(q, st.off24, st.noff24);
+        q += lz_put_stream_huf(q, st.flags, st.nflags, ws, &hf);       // LIZARD_FLAG_FLAGS = 2
+        q += lz_put_stream_huf(q, st.lit, st.nlit, ws, &hl);           // LIZARD_FLAG_LITERALS = 1
+        total = (u32)(q - op);
+        if (lz_lane() == 0) op[0] = (u8)(hl * 1u + hf * 2u);
+        raw = total + total / 32u + 512u > n;                          // lizard_compress.c:228
+    }
+    if (raw) {
+        lz_wave_sync();
+        if (lz_lane() == 0) { op[0] = 128; lz_st24(op + 1, n); }
+        lz_copy(op + 4, in, n);
+        return n + 4u;
+    }
+    return total;
+}
+
 // ---- one API block: reference Lizard_compress_extState on a zeroed state (lizard_compress.c:583) ----
 // dst must have room for Lizard_compressBound(n) bytes. Returns the compressed size (uniform).
-template <int HASHLOG, int TAGLOG>
+// `tag` must provide max(2^TAGLOG bytes, HUF ? 4*LZ_HUF_WS_WORDS : 0) bytes of 4-byte aligned LDS.
+template <int HASHLOG, int TAGLOG, bool HUF>
 LZ_DEV u32 lz_compress_block_fast(const u8* src, u32 n, u8* dst, u32 level, u32* table, u8* tag, u8* scratch)
 {
     const u32 lane = lz_lane();
@@ -294,7 +327,8 @@ LZ_DEV u32 lz_compress_block_fast(const u8* src, u32 n, u8* dst, u32 level, u32*
         const u32 part = (n - pos) < LZ_SUBBLOCK ? (n - pos) : LZ_SUBBLOCK;
         st.nlit = st.nflags = st.noff16 = st.noff24 = 0;      // Lizard_initBlock, :130-138
         lz_parse_fast<HASHLOG, TAGLOG>(src, pos, pos + part, table, tag, st);
-        op += lz_write_subblock_raw_streams(src + pos, part, dst + op, st);
+        if (HUF) op += lz_write_subblock_huf(src + pos, part, dst + op, st, (u32*)tag);
+        else     op += lz_write_subblock_raw_streams(src + pos, part, dst + op, st);
         lz_wave_sync();                                       // scratch is reused by the next sub-block
         pos += part;
     }

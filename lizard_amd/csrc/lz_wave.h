@@ -50,8 +50,28 @@ LZ_DEV u32 lz_ctz64(u64 m) { return (u32)__builtin_ctzll(m); }         // m != 0
 LZ_DEV u32 lz_clz64(u64 m) { return (u32)__builtin_clzll(m); }         // m != 0
 LZ_DEV u32 lz_popc64(u64 m) { return (u32)__builtin_popcountll(m); }
 
-// LDS atomic add (histograms)
-LZ_DEV u32 lz_lds_atomic_add(u32* p, u32 v) { return atomicAdd(p, v); }
+// LDS atomics (histograms, bit-string assembly); results unused -> ds_add_u32 / ds_or_b32 without return
+LZ_DEV void lz_lds_atomic_add(u32* p, u32 v) { atomicAdd(p, v); }
+LZ_DEV void lz_lds_atomic_or(u32* p, u32 v) { atomicOr(p, v); }
+
+// Wave-wide reductions / exclusive prefix sum over all 64 lanes (every lane must call).
+LZ_DEV u32 lz_wave_reduce_add(u32 v)
+{
+    for (u32 d = 32; d > 0; d >>= 1) v += lz_shfl(v, lz_lane() ^ d);
+    return lz_uniform(v);
+}
+LZ_DEV u32 lz_wave_reduce_max(u32 v)
+{
+    for (u32 d = 32; d > 0; d >>= 1) { const u32 o = lz_shfl(v, lz_lane() ^ d); v = o > v ? o : v; }
+    return lz_uniform(v);
+}
+LZ_DEV u32 lz_wave_scan_excl_add(u32 v)
+{
+    const u32 lane = lz_lane();
+    u32 incl = v;
+    for (u32 d = 1; d < 64; d <<= 1) { const u32 o = lz_shfl(incl, lane - d); if (lane >= d) incl += o; }
+    return incl - v;
+}
 
 // Unaligned little-endian loads/stores from global memory.  gfx950 global/flat accesses have no
 // alignment requirement (unaligned access mode), so these compile to single dword/dwordx2 ops.

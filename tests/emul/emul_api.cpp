@@ -6,11 +6,11 @@
 namespace {
 struct Args { const u8* src; u32 n; u8* dst; u32 level; u32* table; u8* tag; u8* scratch; u32 result; };
 
-template <int HASHLOG, int TAGLOG>
+template <int HASHLOG, int TAGLOG, bool HUF>
 void entry_fast(void* a)
 {
     Args* x = (Args*)a;
-    u32 r = lz_compress_block_fast<HASHLOG, TAGLOG>(x->src, x->n, x->dst, x->level, x->table, x->tag, x->scratch);
+    u32 r = lz_compress_block_fast<HASHLOG, TAGLOG, HUF>(x->src, x->n, x->dst, x->level, x->table, x->tag, x->scratch);
     if (lz_lane() == 0) x->result = r;
 }
 }  // namespace
@@ -24,16 +24,43 @@ extern "C" int emul_compress_block(const void* src, int n, void* dst, int level,
     Args a;
     int base = level >= 30 ? level - 20 : level;
     int hashLog = base == 10 ? 12 : base == 11 ? 18 : 0;
-    if (!hashLog || level >= 30) return -1;
+    if (!hashLog) return -1;
     a.src = (const u8*)src; a.n = (u32)n; a.dst = (u8*)dst; a.level = (u32)level; a.result = 0;
     a.table = (u32*)malloc(sizeof(u32) << hashLog);
-    a.tag = (u8*)malloc(4096);
+    a.tag = (u8*)malloc(8192);
     a.scratch = (u8*)malloc(LZ_SCRATCH_BYTES);
     memset(a.table, 0xA5, sizeof(u32) << hashLog);   // garbage: the kernel must initialise its state
-    memset(a.tag, 0x5A, 4096);
+    memset(a.tag, 0x5A, 8192);
     memset(a.scratch, 0xCC, LZ_SCRATCH_BYTES);
-    if (hashLog == 12) lzemu::run_wave(entry_fast<12, 12>, &a, seed);
-    else               lzemu::run_wave(entry_fast<18, 12>, &a, seed);
+    static_assert(4 * LZ_HUF_WS_WORDS <= 8192, "emulated LDS workspace too small");
+    if (hashLog == 12) lzemu::run_wave(level >= 30 ? entry_fast<12, 12, true> : entry_fast<12, 12, false>, &a, seed);
+    else               lzemu::run_wave(level >= 30 ? entry_fast<18, 12, true> : entry_fast<18, 12, false>, &a, seed);
     free(a.table); free(a.tag); free(a.scratch);
+    return (int)a.result;
+}
+
+// One Huffman-candidate stream through lz_put_stream_huf (Lizard_writeStream semantics):
+// out receives LE24 n ‖ LE24 c ‖ payload (accepted) or LE24 n ‖ raw bytes; returns bytes written,
+// *huffed tells which.
+namespace {
+struct HufArgs { const u8* stream; u32 n; u8* out; u32* ws; u32 result; u32 huffed; };
+void entry_huf(void* a)
+{
+    HufArgs* x = (HufArgs*)a;
+    u32 h = 0;
+    u32 r = lz_put_stream_huf(x->out, x->stream, x->n, x->ws, &h);
+    if (lz_lane() == 0) { x->result = r; x->huffed = h; }
+}
+}  // namespace
+
+extern "C" int emul_put_stream_huf(const void* stream, int n, void* out, int* huffed, unsigned seed)
+{
+    HufArgs a;
+    a.stream = (const u8*)stream; a.n = (u32)n; a.out = (u8*)out; a.result = 0; a.huffed = 0;
+    a.ws = (u32*)malloc(4 * LZ_HUF_WS_WORDS);
+    memset(a.ws, 0x77, 4 * LZ_HUF_WS_WORDS);
+    lzemu::run_wave(entry_huf, &a, seed);
+    free(a.ws);
+    *huffed = (int)a.huffed;
     return (int)a.result;
 }

@@ -105,7 +105,26 @@ LZ_DEV u32 lz_ctz64(u64 m) { return (u32)__builtin_ctzll(m); }
 LZ_DEV u32 lz_clz64(u64 m) { return (u32)__builtin_clzll(m); }
 LZ_DEV u32 lz_popc64(u64 m) { return (u32)__builtin_popcountll(m); }
 
-LZ_DEV u32 lz_lds_atomic_add(u32* p, u32 v) { u32 o = *p; *p = o + v; return o; }
+LZ_DEV void lz_lds_atomic_add(u32* p, u32 v) { *p += v; }
+LZ_DEV void lz_lds_atomic_or(u32* p, u32 v) { *p |= v; }
+
+LZ_DEV u32 lz_wave_reduce_add(u32 v)
+{
+    for (u32 d = 32; d > 0; d >>= 1) v += lz_shfl(v, lz_lane() ^ d);
+    return lz_uniform(v);
+}
+LZ_DEV u32 lz_wave_reduce_max(u32 v)
+{
+    for (u32 d = 32; d > 0; d >>= 1) { const u32 o = lz_shfl(v, lz_lane() ^ d); v = o > v ? o : v; }
+    return lz_uniform(v);
+}
+LZ_DEV u32 lz_wave_scan_excl_add(u32 v)
+{
+    const u32 lane = lz_lane();
+    u32 incl = v;
+    for (u32 d = 1; d < 64; d <<= 1) { const u32 o = lz_shfl(incl, lane - d); if (lane >= d) incl += o; }
+    return incl - v;
+}
 
 LZ_DEV u32 lz_ld32(const u8* p) { u32 v; memcpy(&v, p, 4); return v; }
 LZ_DEV u64 lz_ld64(const u8* p) { u64 v; memcpy(&v, p, 8); return v; }

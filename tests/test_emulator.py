@@ -13,7 +13,7 @@ import util
 with open(os.path.join(util.GOLDEN_DIR, "reference_vectors.json")) as f:
     GOLDEN = json.load(f)
 
-EMUL_LEVELS = [10, 11]
+EMUL_LEVELS = [10, 11, 30, 31]
 
 
 def emul_compress(data, level, seed=1):
@@ -40,3 +40,40 @@ def test_emulated_kernel_schedule_independent():
     want = util.oracle_compress(data, 10)
     for seed in (1, 2, 3, 12345):
         assert emul_compress(data, 10, seed) == want
+
+
+def test_emulated_huffman_stream_vs_oracle():
+    """lz_put_stream_huf (Lizard_writeStream + HUF_compress) on synthetic symbol distributions that
+    exercise RLE, 'not compressible', the depth limiter, FSE and raw weight headers."""
+    import random
+    import numpy as np
+    emu = util.emulator()
+    emu.emul_put_stream_huf.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_uint]
+    orc = util.oracle()
+    rnd = random.Random(11); rs = np.random.RandomState(3)
+    huffed = 0
+    for trial in range(60):
+        n = rnd.choice([1024, 1025, 1500, 4001, 4002, 4003, 20000, 131056, rnd.randrange(1025, 60000)])
+        kind = trial % 6
+        if kind == 0: d = rs.randint(0, 256, n)
+        elif kind == 1: d = rs.randint(0, rnd.randrange(1, 20), n)
+        elif kind == 2: d = np.minimum(rs.geometric(rnd.uniform(0.02, 0.9), n), 255)
+        elif kind == 3: d = np.full(n, 9)
+        elif kind == 4:
+            w = np.array([2.0 ** (-i * rnd.uniform(0.3, 1.5)) for i in range(rnd.randrange(2, 256))]); w /= w.sum()
+            d = rs.choice(len(w), n, p=w)
+        else: d = np.abs(rs.normal(128, rnd.uniform(1, 60), n)).astype(np.int64) % 256
+        data = d.astype(np.uint8).tobytes()
+        cap = n + (n >> 8) + 8 + 129 + 64
+        tmp = ctypes.create_string_buffer(cap)
+        c = orc.lzo_huf_compress(tmp, cap, data, n) if n > 1024 else 0
+        hdr = bytes([n & 255, (n >> 8) & 255, n >> 16])
+        if n > 1024 and c != (1 << 64) - 1 and c > 0 and c + c // 8 + 512 < n:
+            want, wh = hdr + bytes([c & 255, (c >> 8) & 255, c >> 16]) + tmp.raw[:c], 1
+        else:
+            want, wh = hdr + data, 0
+        out = ctypes.create_string_buffer(n + 2048); h = ctypes.c_int(0)
+        r = emu.emul_put_stream_huf(ctypes.create_string_buffer(data, n), n, out, ctypes.byref(h), trial + 1)
+        assert (out.raw[:r], h.value) == (want, wh), (trial, kind, n)
+        huffed += wh
+    assert huffed > 10
