@@ -38,8 +38,28 @@ __global__ __launch_bounds__(64) void lz_fast12_kernel(LzBatch a)
         b = lz_uniform(b);
         if (b >= a.nBlocks) break;
         const u32 n = (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
-        const u32 c = lz_compress_block_fast<12, 12, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
+        const u32 c = lz_compress_block<LZ_PARSER_FAST, 12, 12, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
                                                      a.level, table, tag, scratch);
+        if (lz_lane() == 0) a.sizes[b] = c;
+    }
+}
+
+// level 21/41 parser (priceFast + LIZv1): 2^14-entry table = 64 KiB of LDS per wave -> 2 waves per CU.
+template <bool HUF>
+__global__ __launch_bounds__(64) void lz_pricefast14_kernel(LzBatch a)
+{
+    __shared__ u32 table[1u << 14];
+    __shared__ u32 tagws[HUF ? LZ_HUF_WS_WORDS : 1024u];
+    u8* tag = (u8*)tagws;
+    u8* scratch = a.scratch + (u64)blockIdx.x * LZ_SCRATCH_BYTES;
+    for (;;) {
+        u32 b = 0;
+        if (lz_lane() == 0) b = atomicAdd(a.counter, 1u);
+        b = lz_uniform(b);
+        if (b >= a.nBlocks) break;
+        const u32 n = (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
+        const u32 c = lz_compress_block<LZ_PARSER_PRICEFAST, 14, 12, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
+                                                                        a.level, table, tag, scratch);
         if (lz_lane() == 0) a.sizes[b] = c;
     }
 }
@@ -58,6 +78,7 @@ struct Ctx {
     int   cus = 0;
     int   waves = 0;            // persistent grid size (level 10)
     int   wavesHuf = 0;         // persistent grid size (level 30: larger LDS workspace)
+    int   wavesPf = 0, wavesPfHuf = 0;   // levels 21 / 41
     u8*   scratch = nullptr;
     u32*  counter = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -97,11 +118,18 @@ int ctx_init_locked()
     int perCu = 0, perCuHuf = 0;
     LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, lz_fast12_kernel<false>, 64, 0));
     LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuHuf, lz_fast12_kernel<true>, 64, 0));
+    int perCuPf = 0, perCuPfHuf = 0;
+    LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuPf, lz_pricefast14_kernel<false>, 64, 0));
+    LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuPfHuf, lz_pricefast14_kernel<true>, 64, 0));
     if (perCu < 1) perCu = 1;
     if (perCuHuf < 1) perCuHuf = 1;
+    if (perCuPf < 1) perCuPf = 1;
+    if (perCuPfHuf < 1) perCuPfHuf = 1;
     g_ctx.cus = prop.multiProcessorCount;
     g_ctx.waves = g_ctx.cus * perCu;
     g_ctx.wavesHuf = g_ctx.cus * perCuHuf;
+    g_ctx.wavesPf = g_ctx.cus * perCuPf;
+    g_ctx.wavesPfHuf = g_ctx.cus * perCuPfHuf;
     LZ_HIP(hipMalloc((void**)&g_ctx.scratch, (size_t)g_ctx.waves * LZ_SCRATCH_BYTES));
     LZ_HIP(hipMalloc((void**)&g_ctx.counter, 64));
     LZ_HIP(hipEventCreate(&g_ctx.ev0));
@@ -127,12 +155,16 @@ int launch_locked(const void* d_src, size_t nBlocks, size_t blockSize, size_t la
     int lv = level > LIZARD_MAX_CLEVEL ? LIZARD_MAX_CLEVEL : level;
     if (lv < LIZARD_MIN_CLEVEL) lv = LIZARD_DEFAULT_CLEVEL;
     a.level = (u32)lv;
-    const size_t resident = (size_t)(lv >= 30 ? g_ctx.wavesHuf : g_ctx.waves);
+    const size_t resident = (size_t)(lv == 10 ? g_ctx.waves : lv == 30 ? g_ctx.wavesHuf : lv == 21 ? g_ctx.wavesPf : g_ctx.wavesPfHuf);
     const u32 grid = (u32)(nBlocks < resident ? nBlocks : resident);
     LZ_HIP(hipMemsetAsync(g_ctx.counter, 0, 4, stream));
     LZ_HIP(hipEventRecord(g_ctx.ev0, stream));
-    if (lv == 30) hipLaunchKernelGGL(lz_fast12_kernel<true>, dim3(grid), dim3(64), 0, stream, a);
-    else          hipLaunchKernelGGL(lz_fast12_kernel<false>, dim3(grid), dim3(64), 0, stream, a);
+    switch (lv) {
+    case 10: hipLaunchKernelGGL(lz_fast12_kernel<false>, dim3(grid), dim3(64), 0, stream, a); break;
+    case 30: hipLaunchKernelGGL(lz_fast12_kernel<true>, dim3(grid), dim3(64), 0, stream, a); break;
+    case 21: hipLaunchKernelGGL(lz_pricefast14_kernel<false>, dim3(grid), dim3(64), 0, stream, a); break;
+    default: hipLaunchKernelGGL(lz_pricefast14_kernel<true>, dim3(grid), dim3(64), 0, stream, a); break;
+    }
     LZ_HIP(hipGetLastError());
     LZ_HIP(hipEventRecord(g_ctx.ev1, stream));
     g_ctx.timed = true;
@@ -157,7 +189,7 @@ int LizardGPU_levelSupported(int level)
 {
     if (level > LIZARD_MAX_CLEVEL) level = LIZARD_MAX_CLEVEL;        // reference lizard_compress.c:303-308
     if (level < LIZARD_MIN_CLEVEL) level = LIZARD_DEFAULT_CLEVEL;
-    return level == 10 || level == 30;
+    return level == 10 || level == 30 || level == 21 || level == 41;
 }
 
 int LizardGPU_setDevice(int device)

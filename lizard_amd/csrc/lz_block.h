@@ -244,8 +244,11 @@ tail:
     lz_emit_last_literals(src, anchor, E, st);                           // fast.h:187-190
 }
 
-// ---- sub-block container (reference lib/lizard_compress.c:141-250) -------------------------------
 LZ_DEV void lz_st24(u8* p, u32 v) { p[0] = (u8)v; p[1] = (u8)(v >> 8); p[2] = (u8)(v >> 16); }
+
+#include "lz_pricefast.h"   // priceFast parser + LIZv1 encoder (uses the helpers above)
+
+// ---- sub-block container (reference lib/lizard_compress.c:141-250) -------------------------------
 
 // Raw stream: LE24 length + bytes (lizard_compress.c:176-182). Returns bytes written. All lanes call.
 LZ_DEV u32 lz_put_stream_raw(u8* op, const u8* stream, u32 n)
@@ -313,8 +316,11 @@ LZ_DEV u32 lz_write_subblock_huf(const u8* in, u32 n, u8* op, LzStreams& st, u32
 // ---- one API block: reference Lizard_compress_extState on a zeroed state (lizard_compress.c:583) ----
 // dst must have room for Lizard_compressBound(n) bytes. Returns the compressed size (uniform).
 // `tag` must provide max(2^TAGLOG bytes, HUF ? 4*LZ_HUF_WS_WORDS : 0) bytes of 4-byte aligned LDS.
-template <int HASHLOG, int TAGLOG, bool HUF>
-LZ_DEV u32 lz_compress_block_fast(const u8* src, u32 n, u8* dst, u32 level, u32* table, u8* tag, u8* scratch)
+// PARSER: 0 = fastSmall/fast + fastLZ4 codewords, 1 = priceFast + LIZv1 codewords.
+#define LZ_PARSER_FAST      0
+#define LZ_PARSER_PRICEFAST 1
+template <int PARSER, int HASHLOG, int TAGLOG, bool HUF>
+LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, u32* table, u8* tag, u8* scratch)
 {
     const u32 lane = lz_lane();
     LzStreams st;
@@ -326,7 +332,8 @@ LZ_DEV u32 lz_compress_block_fast(const u8* src, u32 n, u8* dst, u32 level, u32*
     for (u32 pos = 0; pos < n; ) {                            // lizard_compress.c:494
         const u32 part = (n - pos) < LZ_SUBBLOCK ? (n - pos) : LZ_SUBBLOCK;
         st.nlit = st.nflags = st.noff16 = st.noff24 = 0;      // Lizard_initBlock, :130-138
-        lz_parse_fast<HASHLOG, TAGLOG>(src, pos, pos + part, table, tag, st);
+        if (PARSER == LZ_PARSER_FAST) lz_parse_fast<HASHLOG, TAGLOG>(src, pos, pos + part, table, tag, st);
+        else                          lz_parse_pricefast<HASHLOG, TAGLOG>(src, pos, pos + part, table, tag, st);
         if (HUF) op += lz_write_subblock_huf(src + pos, part, dst + op, st, (u32*)tag);
         else     op += lz_write_subblock_raw_streams(src + pos, part, dst + op, st);
         lz_wave_sync();                                       // scratch is reused by the next sub-block

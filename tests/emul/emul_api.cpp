@@ -6,11 +6,11 @@
 namespace {
 struct Args { const u8* src; u32 n; u8* dst; u32 level; u32* table; u8* tag; u8* scratch; u32 result; };
 
-template <int HASHLOG, int TAGLOG, bool HUF>
-void entry_fast(void* a)
+template <int PARSER, int HASHLOG, int TAGLOG, bool HUF>
+void entry_block(void* a)
 {
     Args* x = (Args*)a;
-    u32 r = lz_compress_block_fast<HASHLOG, TAGLOG, HUF>(x->src, x->n, x->dst, x->level, x->table, x->tag, x->scratch);
+    u32 r = lz_compress_block<PARSER, HASHLOG, TAGLOG, HUF>(x->src, x->n, x->dst, x->level, x->table, x->tag, x->scratch);
     if (lz_lane() == 0) x->result = r;
 }
 }  // namespace
@@ -23,7 +23,7 @@ extern "C" int emul_compress_block(const void* src, int n, void* dst, int level,
 {
     Args a;
     int base = level >= 30 ? level - 20 : level;
-    int hashLog = base == 10 ? 12 : base == 11 ? 18 : 0;
+    int hashLog = base == 10 ? 12 : base == 11 ? 18 : base == 21 ? 14 : base == 22 ? 18 : 0;
     if (!hashLog) return -1;
     a.src = (const u8*)src; a.n = (u32)n; a.dst = (u8*)dst; a.level = (u32)level; a.result = 0;
     a.table = (u32*)malloc(sizeof(u32) << hashLog);
@@ -33,8 +33,13 @@ extern "C" int emul_compress_block(const void* src, int n, void* dst, int level,
     memset(a.tag, 0x5A, 8192);
     memset(a.scratch, 0xCC, LZ_SCRATCH_BYTES);
     static_assert(4 * LZ_HUF_WS_WORDS <= 8192, "emulated LDS workspace too small");
-    if (hashLog == 12) lzemu::run_wave(level >= 30 ? entry_fast<12, 12, true> : entry_fast<12, 12, false>, &a, seed);
-    else               lzemu::run_wave(level >= 30 ? entry_fast<18, 12, true> : entry_fast<18, 12, false>, &a, seed);
+    const bool huf = level >= 30;
+    switch (base) {
+    case 10: lzemu::run_wave(huf ? entry_block<LZ_PARSER_FAST, 12, 12, true> : entry_block<LZ_PARSER_FAST, 12, 12, false>, &a, seed); break;
+    case 11: lzemu::run_wave(huf ? entry_block<LZ_PARSER_FAST, 18, 12, true> : entry_block<LZ_PARSER_FAST, 18, 12, false>, &a, seed); break;
+    case 21: lzemu::run_wave(huf ? entry_block<LZ_PARSER_PRICEFAST, 14, 12, true> : entry_block<LZ_PARSER_PRICEFAST, 14, 12, false>, &a, seed); break;
+    default: lzemu::run_wave(huf ? entry_block<LZ_PARSER_PRICEFAST, 18, 12, true> : entry_block<LZ_PARSER_PRICEFAST, 18, 12, false>, &a, seed); break;
+    }
     free(a.table); free(a.tag); free(a.scratch);
     return (int)a.result;
 }

@@ -13,7 +13,7 @@ import util
 with open(os.path.join(util.GOLDEN_DIR, "reference_vectors.json")) as f:
     GOLDEN = json.load(f)
 
-EMUL_LEVELS = [10, 11, 30, 31]
+EMUL_LEVELS = [10, 11, 21, 22, 30, 31, 41, 42]
 
 
 def emul_compress(data, level, seed=1):
