@@ -109,7 +109,8 @@ def main():
     src = torch.empty(nb * bs, dtype=torch.uint8, device=dev)
     dst = torch.empty(nb * stride, dtype=torch.uint8, device=dev)
     sizes = torch.zeros(nb, dtype=torch.int32, device=dev)
-    gathered = torch.zeros(world * nb, dtype=torch.int32, device=dev) if world > 1 else None
+    from lizard_amd.sharding import gather_block_sizes
+    gathered = None
     stream = torch.cuda.current_stream(dev)
     _lib.check(L.LizardGPU_datagen_device(src.data_ptr(), nb, bs, 0.5, 0.0, rank * nb, ctypes.c_void_p(stream.cuda_stream)),
                "LizardGPU_datagen_device")
@@ -118,12 +119,13 @@ def main():
     kernel_ms = []
 
     def step(timed):
+        nonlocal gathered
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         api.compress_blocks_device(src, bs, args.level, dst=dst, sizes=sizes)
         e1.record(stream)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, sizes)      # RCCL over xGMI: 4 B per block per rank
+        if world > 1:                                         # RCCL over xGMI: 4 B per block per rank
+            gathered = gather_block_sizes(sizes, world * nb)  # -> sizes + global output offsets on every rank
         if timed:
             kernel_ms.append((e0, e1))
 
@@ -151,9 +153,9 @@ def main():
     out_bytes = int(sizes.to(torch.int64).sum().item())
     tot_in, tot_out = in_bytes * world, out_bytes
     if world > 1:
-        tot_out = int(gathered.to(torch.int64).sum().item())
-        offsets = torch.cumsum(gathered.to(torch.int64), 0) - gathered      # global exclusive prefix sum of output offsets
-        assert int(offsets[-1].item()) + int(gathered[-1].item()) == tot_out
+        all_sizes, offsets = gathered
+        tot_out = int(all_sizes.to(torch.int64).sum().item())
+        assert int(offsets[-1].item()) + int(all_sizes[-1].item()) == tot_out
 
     verified = 0
     if rank == 0 and args.verify > 0:
