@@ -33,14 +33,14 @@ __global__ __launch_bounds__(64) void lz_fast12_kernel(LzBatch a)
     u8* tag = (u8*)tagws;
     u8* scratch = a.scratch + (u64)blockIdx.x * LZ_SCRATCH_BYTES;
     for (;;) {
-        u32 b = 0;
-        if (lz_lane() == 0) b = atomicAdd(a.counter, 1u);
-        b = lz_uniform(b);
+        lz_converge();
+        const u32 b = lz_claim_index(a.counter);
         if (b >= a.nBlocks) break;
         const u32 n = (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
         const u32 c = lz_compress_block<LZ_PARSER_FAST, 12, 12, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
                                                      a.level, table, tag, scratch);
         if (lz_lane() == 0) a.sizes[b] = c;
+        lz_converge();
     }
 }
 
@@ -53,14 +53,14 @@ __global__ __launch_bounds__(64) void lz_pricefast14_kernel(LzBatch a)
     u8* tag = (u8*)tagws;
     u8* scratch = a.scratch + (u64)blockIdx.x * LZ_SCRATCH_BYTES;
     for (;;) {
-        u32 b = 0;
-        if (lz_lane() == 0) b = atomicAdd(a.counter, 1u);
-        b = lz_uniform(b);
+        lz_converge();
+        const u32 b = lz_claim_index(a.counter);
         if (b >= a.nBlocks) break;
         const u32 n = (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
         const u32 c = lz_compress_block<LZ_PARSER_PRICEFAST, 14, 12, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
                                                                         a.level, table, tag, scratch);
         if (lz_lane() == 0) a.sizes[b] = c;
+        lz_converge();
     }
 }
 

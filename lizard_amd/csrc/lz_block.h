@@ -139,6 +139,7 @@ LZ_DEV void lz_emit_lz4(const u8* src, u32 anchor, u32 P, u32 ml, u32 M, LzStrea
         out[i] = (u8)b;
     }
     if (lane == 0) st.flags[st.nflags] = (u8)token;
+    lz_converge();
     st.nlit += R; st.nflags += 1u;
 }
 
@@ -254,6 +255,7 @@ LZ_DEV void lz_st24(u8* p, u32 v) { p[0] = (u8)v; p[1] = (u8)(v >> 8); p[2] = (u
 LZ_DEV u32 lz_put_stream_raw(u8* op, const u8* stream, u32 n)
 {
     if (lz_lane() == 0) lz_st24(op, n);
+    lz_converge();
     lz_copy(op + 3, stream, n);
     return 3u + n;
 }
@@ -268,12 +270,14 @@ LZ_DEV u32 lz_write_subblock_raw_streams(const u8* in, u32 n, u8* op, LzStreams&
     const bool raw = st.nlit < LZ_LASTLITERALS || sum + 16u > n || total + total / 32u + 512u > n;
     if (raw) {
         if (lz_lane() == 0) { op[0] = 128; lz_st24(op + 1, n); }   // LIZARD_FLAG_UNCOMPRESSED, :239-244
+        lz_converge();
         lz_copy(op + 4, in, n);
         return n + 4u;
     }
     lz_wave_sync();                                           // stream bytes written by other lanes
     u8* q = op;
     if (lz_lane() == 0) { q[0] = 0; lz_st24(q + 1, 0); }      // header byte, empty `len` stream (:203-207)
+    lz_converge();
     q += 4;
     q += lz_put_stream_raw(q, st.off16, st.noff16);           // :209
     q += lz_put_stream_raw(q, st.off24, st.noff24);           // :212
@@ -295,6 +299,7 @@ LZ_DEV u32 lz_write_subblock_huf(const u8* in, u32 n, u8* op, LzStreams& st, u32
         u32 hf = 0, hl = 0;
         u8* q = op + 1;
         if (lz_lane() == 0) lz_st24(q, 0);                             // empty `len` stream
+        lz_converge();
         q += 3;
         q += lz_put_stream_raw(q, st.off16, st.noff16);
         q += lz_put_stream_raw(q, st.off24, st.noff24);
@@ -302,11 +307,13 @@ LZ_DEV u32 lz_write_subblock_huf(const u8* in, u32 n, u8* op, LzStreams& st, u32
         q += lz_put_stream_huf(q, st.lit, st.nlit, ws, &hl);           // LIZARD_FLAG_LITERALS = 1
         total = (u32)(q - op);
         if (lz_lane() == 0) op[0] = (u8)(hl * 1u + hf * 2u);
+        lz_converge();
         raw = total + total / 32u + 512u > n;                          // lizard_compress.c:228
     }
     if (raw) {
         lz_wave_sync();
         if (lz_lane() == 0) { op[0] = 128; lz_st24(op + 1, n); }
+        lz_converge();
         lz_copy(op + 4, in, n);
         return n + 4u;
     }
@@ -328,6 +335,7 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, u32* tabl
     for (u32 i = lane; i < (1u << HASHLOG); i += 64u) table[i] = LZ_EMPTY;
     lz_wave_sync();
     if (lane == 0) dst[0] = (u8)level;                        // lizard_compress.c:488
+    lz_converge();
     u32 op = 1u;                                              // uniform
     for (u32 pos = 0; pos < n; ) {                            // lizard_compress.c:494
         const u32 part = (n - pos) < LZ_SUBBLOCK ? (n - pos) : LZ_SUBBLOCK;

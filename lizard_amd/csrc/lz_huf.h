@@ -346,6 +346,7 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
     *huffed = 0;
     if (n <= 1024u) {                                          // lizard_compress.c:143
         if (lane == 0) { op[0] = (u8)n; op[1] = (u8)(n >> 8); op[2] = (u8)(n >> 16); }
+        lz_converge();
         for (u32 i = lane * 4u; i < (n & ~3u); i += 256u) lz_st32(op + 3 + i, lz_ld32(stream + i));
         for (u32 i = (n & ~3u) + lane; i < n; i += 64u) op[3 + i] = stream[i];
         return 3u + n;
@@ -387,6 +388,7 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
     u32 csize = 0;                                             // uniform
     if (largest == n) {                                        // single symbol: RLE, 1 byte (huf_compress.c:544)
         if (lane == 0) payload[0] = stream[0];
+        lz_converge();
         csize = 1; accept = true;
     } else if (largest > (n >> 7) + 1u) {                      // :545 otherwise "not compressible"
         // ---- sort: node[rank] = (count, symbol), descending count, ties ascending symbol (:305-325) ----
@@ -409,7 +411,8 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
         }
         lz_wave_sync();
         // ---- lane 0: tree, depth limit, canonical codes, weight header ----
-        u32 hdr = 0;                                           // header size, 0 = reference error -> raw
+        u32 hdr = 0;                                           // header size, 0 = reference error -> raw (lane 0's value,
+                                                               // broadcast through LDS: fse[159])
         u32 huffLog = lz_fse_optimal_tablelog(LZ_HUF_DEFAULTLOG, n, maxSym, 1u);   // HUF_optimalTableLog :66
         if (lane == 0) {
             const u32 START = 256u;                            // STARTNODE, :333
@@ -455,9 +458,10 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
                 for (u32 s = 0; s < maxSym; s += 2u) payload[s / 2u + 1u] = (u8)((wt[s] << 4) + wt[s + 1u]);
                 hdr = (maxSym + 1u) / 2u + 1u;
             }
+            fse[159] = hdr;
         }
         lz_wave_sync();
-        hdr = lz_readlane(hdr, 0);
+        hdr = lz_uniform(fse[159]);
         if (hdr != 0 && hdr + 12u < n) {                       // :556
             // ---- exact stream sizes: sum of code lengths per segment (huf_compress.c:473-513) ----
             const u32 seg = (n + 3u) / 4u;
@@ -474,6 +478,7 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
                 if (lane == 0) {
                     lz_st16(payload + hdr, segBytes[0]); lz_st16(payload + hdr + 2, segBytes[1]); lz_st16(payload + hdr + 4, segBytes[2]);
                 }
+                lz_converge();
                 u8* q = payload + hdr + 6u;
                 for (u32 k = 0; k < 4u; k++) {
                     const u32 a = k * seg, b = (k == 3u) ? n : (k + 1u) * seg;
@@ -486,10 +491,12 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
     }
     if (accept && csize + csize / 8u + 512u < n) {             // lizard_compress.c:157 (also for the RLE byte)
         if (lane == 0) { op[0] = (u8)n; op[1] = (u8)(n >> 8); op[2] = (u8)(n >> 16); op[3] = (u8)csize; op[4] = (u8)(csize >> 8); op[5] = (u8)(csize >> 16); }
+        lz_converge();
         *huffed = 1;
         return 6u + csize;
     }
     if (lane == 0) { op[0] = (u8)n; op[1] = (u8)(n >> 8); op[2] = (u8)(n >> 16); }
+    lz_converge();
     for (u32 i = lane * 4u; i < (n & ~3u); i += 256u) lz_st32(op + 3 + i, lz_ld32(stream + i));
     for (u32 i = (n & ~3u) + lane; i < n; i += 64u) op[3 + i] = stream[i];
     return 3u + n;

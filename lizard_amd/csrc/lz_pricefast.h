@@ -60,6 +60,7 @@ LZ_DEV void lz_emit_lizv1(const u8* src, u32 anchor, u32 P, u32 ml, u32 M, LzStr
             if (off != 0) lz_st16(st.off16 + st.noff16, off);
         }
     }
+    lz_converge();
     if (longOff) { st.nflags += (L > 0) ? 2u : 1u; st.noff24 += 3u; last_off = off; }
     else { st.nflags += 1u; if (off != 0) { st.noff16 += 2u; last_off = off; } }
 }

@@ -46,6 +46,21 @@ LZ_DEV void lz_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// Re-convergence point. LLVM may jump-thread two `if (lane == 0)` regions into separate per-lane paths
+// (seen on ROCm 7.2: the claim loop below split lane 0 from lanes 1..63 around its back-edge, so 63
+// lanes spun forever); a convergent, side-effecting, non-duplicable marker after every single-lane
+// region and at the top of every wave-uniform loop forces the paths to re-join first. No ISA emitted.
+LZ_DEV void lz_converge() { __builtin_amdgcn_wave_barrier(); }
+
+// Claim the next work item from a device-wide counter: ONE atomic per wave, result wave-uniform.
+// Deliberately branch-free (every lane takes part, only lane 0 adds 1): no single-lane region sits
+// next to the loop back-edge of the caller.
+LZ_DEV u32 lz_claim_index(u32* counter)
+{
+    const u32 old = atomicAdd(counter, lz_lane() == 0 ? 1u : 0u);
+    return lz_readlane(old, 0);
+}
+
 LZ_DEV u32 lz_ctz64(u64 m) { return (u32)__builtin_ctzll(m); }         // m != 0
 LZ_DEV u32 lz_clz64(u64 m) { return (u32)__builtin_clzll(m); }         // m != 0
 LZ_DEV u32 lz_popc64(u64 m) { return (u32)__builtin_popcountll(m); }
