@@ -192,7 +192,8 @@ def main():
             "verified_blocks_bit_exact": verified,
             "roofline": {"bound": "hbm", "achieved": round(alg_bytes / avg_k / 1e9, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(alg_bytes / avg_k / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "lz_fast12_kernel", "avg_kernel_ms": round(avg_k * 1e3, 3),
+                         "kernel": {10: "lz_fast12_kernel<false>", 30: "lz_fast12_kernel<true>", 21: "lz_pricefast14_kernel<false>",
+                                    41: "lz_pricefast14_kernel<true>"}.get(args.level, "?"), "avg_kernel_ms": round(avg_k * 1e3, 3),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not args.no_cpu:

@@ -51,6 +51,8 @@ int main(int argc, char** argv)
     static const int sizes[] = { 1, 20, 21, 100, 4096, 65537, 131072, 131073, 262144, 300000 };
     static const int levels[] = { 10, 30, 21, 41 };
     int nb = argc > 1 ? atoi(argv[1]) : 512, bs = 262144, fails = 0;
+    int only = argc > 2 ? atoi(argv[2]) : 0;          /* restrict to one level */
+    int reps = argc > 3 ? atoi(argv[3]) : 1;          /* repeat the batch (profiling) */
     pthread_t th;
     pthread_create(&th, NULL, watchdog, NULL);
 
@@ -64,7 +66,7 @@ int main(int argc, char** argv)
     for (unsigned li = 0; li < sizeof levels / sizeof *levels; li++) {
         int level = levels[li];
         char name[64];
-        if (!LizardGPU_levelSupported(level)) continue;
+        if (!LizardGPU_levelSupported(level) || (only && level != only)) continue;
         for (unsigned si = 0; si < sizeof sizes / sizeof *sizes; si++) {
             snprintf(name, sizeof name, "L%d one block n=%d", level, sizes[si]);
             g_case = name; g_deadline = 30;
@@ -91,8 +93,11 @@ int main(int argc, char** argv)
             unsigned char* out = malloc((size_t)nb * stride);
             uint32_t* cs = malloc(sizeof(uint32_t) * nb);
             snprintf(name, sizeof name, "L%d batch %d x %d", level, nb, bs); g_case = name; g_deadline = 120;
-            int rc = LizardGPU_compressBlocks_host(buf, nb, bs, bs, out, stride, cs, level);
-            float ms = LizardGPU_lastKernelMs();
+            int rc = 0; float ms = 0;
+            for (int r = 0; r < reps && !rc; r++) {
+                rc = LizardGPU_compressBlocks_host(buf, nb, bs, bs, out, stride, cs, level);
+                ms = LizardGPU_lastKernelMs();
+            }
             g_deadline = 0;
             size_t tot = 0; int bad = rc != 0;
             for (int b = 0; b < nb && !bad; b++) {
