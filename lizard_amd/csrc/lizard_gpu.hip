@@ -23,13 +23,14 @@ struct LzBatch {
     u8* scratch;    u32* counter;
 };
 
-// level 10/30 parser: hash table (2^12 x u32) and the round tag array (2^12 x u8) live in LDS; at
-// level 30 the tag array doubles as the Huffman stage's workspace (the two are never live together).
-template <bool HUF>
+// level 10/30 parser: the 2^12-entry hash table (16 KiB) is the only LDS the parser needs -> 10 waves
+// per CU; level 30 adds the Huffman stage's workspace.  POSBITS 22 (10 check bits per entry) for
+// blocks <= 4 MiB, 32 for larger ones.
+template <bool HUF, int POSBITS>
 __global__ __launch_bounds__(64) void lz_fast12_kernel(LzBatch a)
 {
     __shared__ u32 table[1u << 12];
-    __shared__ u32 tagws[HUF ? LZ_HUF_WS_WORDS : 1024u];
+    __shared__ u32 tagws[HUF ? LZ_HUF_WS_WORDS : 1u];
     u8* tag = (u8*)tagws;
     u8* scratch = a.scratch + (u64)blockIdx.x * LZ_SCRATCH_BYTES;
     for (;;) {
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(64) void lz_fast12_kernel(LzBatch a)
         const u32 b = lz_claim_index(a.counter);
         if (b >= a.nBlocks) break;
         const u32 n = (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
-        const u32 c = lz_compress_block<LZ_PARSER_FAST, 12, 12, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
+        const u32 c = lz_compress_block<LZ_PARSER_FAST, 12, POSBITS, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
                                                      a.level, table, tag, scratch);
         if (lz_lane() == 0) a.sizes[b] = c;
         lz_converge();
@@ -116,8 +117,8 @@ int ctx_init_locked()
     hipDeviceProp_t prop;
     LZ_HIP(hipGetDeviceProperties(&prop, g_want_device));
     int perCu = 0, perCuHuf = 0;
-    LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, lz_fast12_kernel<false>, 64, 0));
-    LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuHuf, lz_fast12_kernel<true>, 64, 0));
+    LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, lz_fast12_kernel<false, 22>, 64, 0));
+    LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuHuf, lz_fast12_kernel<true, 22>, 64, 0));
     int perCuPf = 0, perCuPfHuf = 0;
     LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuPf, lz_pricefast14_kernel<false>, 64, 0));
     LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuPfHuf, lz_pricefast14_kernel<true>, 64, 0));
@@ -160,8 +161,14 @@ int launch_locked(const void* d_src, size_t nBlocks, size_t blockSize, size_t la
     LZ_HIP(hipMemsetAsync(g_ctx.counter, 0, 4, stream));
     LZ_HIP(hipEventRecord(g_ctx.ev0, stream));
     switch (lv) {
-    case 10: hipLaunchKernelGGL(lz_fast12_kernel<false>, dim3(grid), dim3(64), 0, stream, a); break;
-    case 30: hipLaunchKernelGGL(lz_fast12_kernel<true>, dim3(grid), dim3(64), 0, stream, a); break;
+    case 10:
+        if (blockSize <= (4u << 20)) hipLaunchKernelGGL((lz_fast12_kernel<false, 22>), dim3(grid), dim3(64), 0, stream, a);
+        else                         hipLaunchKernelGGL((lz_fast12_kernel<false, 32>), dim3(grid), dim3(64), 0, stream, a);
+        break;
+    case 30:
+        if (blockSize <= (4u << 20)) hipLaunchKernelGGL((lz_fast12_kernel<true, 22>), dim3(grid), dim3(64), 0, stream, a);
+        else                         hipLaunchKernelGGL((lz_fast12_kernel<true, 32>), dim3(grid), dim3(64), 0, stream, a);
+        break;
     case 21: hipLaunchKernelGGL(lz_pricefast14_kernel<false>, dim3(grid), dim3(64), 0, stream, a); break;
     default: hipLaunchKernelGGL(lz_pricefast14_kernel<true>, dim3(grid), dim3(64), 0, stream, a); break;
     }

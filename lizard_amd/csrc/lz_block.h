@@ -151,11 +151,28 @@ LZ_DEV void lz_emit_last_literals(const u8* src, u32 anchor, u32 E, LzStreams& s
 }
 
 // ---- fastSmall / fast parser over one sub-block [S,E) of the block at `src` ----------------------
-// table: 2^HASHLOG u32 positions (block-relative), LZ_EMPTY when never written; persists across the
-//        sub-blocks of one block (reference lizard_compress.c:494-540).  LDS for HASHLOG 12.
-// tag:   2^TAGLOG bytes of LDS, contents irrelevant on entry.
-template <int HASHLOG, int TAGLOG>
-LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, u32* table, u8* tag, LzStreams& st)
+// table: 2^HASHLOG u32 entries, LZ_EMPTY when never written; persists across the sub-blocks of one block
+//        (reference lizard_compress.c:494-540).  LDS for HASHLOG 12.
+// Entry layout (ours; only the parse RESULT is pinned by the reference): low POSBITS bits = position
+// (block-relative), high 32-POSBITS bits = a multiplicative check hash of the 4 bytes at that position.
+// A candidate whose check bits differ from the probing position's cannot pass the reference's 4-byte
+// equality test (fast.h:97), so its bytes are never fetched: most rounds issue no candidate gather at
+// all.  Equal check bits prove nothing; those lanes still load and compare the real 4 bytes.
+// POSBITS 22 serves blocks up to 4 MiB; POSBITS 32 (no check bits) any size.
+template <int POSBITS>
+LZ_DEV u32 lz_entry(u32 p, u32 first4)
+{
+    if constexpr (POSBITS >= 32) return p;
+    else return p | ((first4 * 2654435761u) >> POSBITS << POSBITS);
+}
+template <int POSBITS> LZ_DEV u32 lz_entry_pos(u32 e)
+{
+    if constexpr (POSBITS >= 32) return e;
+    else return e & ((1u << POSBITS) - 1u);
+}
+
+template <int HASHLOG, int POSBITS>
+LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, u32* table, LzStreams& st)
 {
     const u32 lane = lz_lane();
     const u64 laneBit = 1ull << lane;
@@ -166,8 +183,8 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, u32* table, u8* tag, LzSt
     // fast.h:57-58 in block-relative positions: lowLimit is fixed at sub-block entry
     const u32 lowPos = S > LZ_MAX_DIST_LZ4 ? S - LZ_MAX_DIST_LZ4 : 0u;
 
-    if (lane == 0) table[lz_hash5<HASHLOG>(lz_ld64(src + S))] = S;   // fast.h:66
-    lz_wave_sync();
+    if (lane == 0) { const u64 b0 = lz_ld64(src + S); table[lz_hash5<HASHLOG>(b0)] = lz_entry<POSBITS>(S, (u32)b0); }   // fast.h:66
+    lz_lds_sync();
 
     u32 ip = S + 1u;        // uniform: run start, or (special==1) the post-match probe position
     u32 special = 0;        // uniform
@@ -184,47 +201,60 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, u32* table, u8* tag, LzSt
                 p = ip + special + lz_visit_off(v);
                 valid = p + lz_visit_step(v) <= mflimit;                 // fast.h:84, tested before the probe
             }
-            u32 h = 0, e = LZ_EMPTY, first4 = 0;
+            u32 h = 0, e = LZ_EMPTY, first4 = 0, mine = 0;
             if (valid) {
                 const u64 bytes = lz_ld64(src + p);
                 first4 = (u32)bytes;
                 h = lz_hash5<HASHLOG>(bytes);
-                e = table[h];                                            // fast.h:86 (old value)
-                tag[h & ((1u << TAGLOG) - 1u)] = (u8)lane;
+                mine = lz_entry<POSBITS>(p, first4);
+                e = table[h];                                            // fast.h:86 (value before this round)
             }
-            lz_wave_sync();
-            const bool lost = valid && tag[h & ((1u << TAGLOG) - 1u)] != (u8)lane;
+            lz_converge();                                               // every lane has read before any lane puts
+            if (valid) table[h] = mine;                                  // speculative put (fast.h:88); undone below if needed
+            lz_lds_sync();
+            // two visits of this round on one slot: the later must see the earlier's put, in visit order
+            const bool lost = valid && table[h] != mine;
             u64 pend = lz_ballot(lost);                                  // uniform
-            u64 grp = laneBit;                                           // lanes of this round with my hash
+            u64 grp = laneBit;                                           // lanes of this round on my slot
+            const u32 eOld = e;
             if (pend) {
-                // rare-ish path: at least two valid lanes share a tag slot; rebuild exact hash groups
                 while (pend) {
                     const u32 f = lz_ctz64(pend);
                     const u32 hv = lz_readlane(h, f);
-                    const bool mine = valid && h == hv;
-                    const u64 g = lz_ballot(mine);
-                    if (mine) grp = g;
+                    const bool same = valid && h == hv;
+                    const u64 g = lz_ballot(same);
+                    if (same) grp = g;
                     pend &= ~g;
                 }
-                // in-order predecessor inside the round: the reference would have read ITS put
                 const u64 prev = grp & lanesBelow;
                 const u32 j = prev ? 63u - lz_clz64(prev) : lane;
-                const u32 pj = lz_shfl(p, j);
-                if (prev) e = pj;
+                const u32 ej = lz_shfl(mine, j);
+                if (prev) e = ej;
             }
-            // accept test, fast.h:90-97
+            // accept test, fast.h:90-97 (check bits first: they decide whether the 4 bytes are fetched at all)
             bool ok = false;
-            if (valid && e >= lowPos && e < p && p - e <= LZ_MAX_DIST_LZ4 && p - e >= LZ_MIN_OFFSET)
-                ok = lz_ld32(src + e) == first4;
+            {
+                const u32 ep = lz_entry_pos<POSBITS>(e);
+                const bool chk = POSBITS >= 32 || ((e ^ mine) >> (POSBITS & 31)) == 0;
+                if (valid && chk && ep >= lowPos && ep < p && p - ep <= LZ_MAX_DIST_LZ4 && p - ep >= LZ_MIN_OFFSET)
+                    ok = lz_ld32(src + ep) == first4;
+            }
             const u64 okMask = lz_ballot(ok);                            // uniform
             const u64 validMask = lz_ballot(valid);                      // uniform, a prefix of lanes
             u32 w = 0;
             u64 commit = validMask;
             if (okMask) { w = lz_ctz64(okMask); commit = validMask & (~0ull >> (63u - w)); }
-            // table puts in visit order: the last same-hash lane inside `commit` wins (fast.h:88)
-            if ((commit & laneBit) && (grp & commit & ~(lanesBelow | laneBit)) == 0) table[h] = p;
-            lz_wave_sync();
-            if (okMask) { P = lz_readlane(p, w); M = lz_readlane(e, w); break; }
+            // settle the slots: visits after the winner never happened (the reference stopped there)
+            if (valid) {
+                if (grp == laneBit) { if (!(commit & laneBit)) table[h] = eOld; }          // undo my put
+                else {
+                    const u64 c = grp & commit;
+                    if (c) { if (lane == 63u - lz_clz64(c)) table[h] = mine; }             // last committed visit wins
+                    else if (lane == lz_ctz64(grp)) table[h] = eOld;                       // whole group undone
+                }
+            }
+            lz_lds_sync();
+            if (okMask) { P = lz_readlane(p, w); M = lz_readlane(lz_entry_pos<POSBITS>(e), w); break; }
             if (validMask != ~0ull) goto tail;                           // ran into mflimit without a match
             v0 += 64u;
         }
@@ -237,8 +267,8 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, u32* table, u8* tag, LzSt
             ip = P + ml; anchor = ip;
         }
         if (ip > mflimit) goto tail;                                     // fast.h:143
-        if (lane == 0) table[lz_hash5<HASHLOG>(lz_ld64(src + ip - 2u))] = ip - 2u;   // fast.h:146
-        lz_wave_sync();
+        if (lane == 0) { const u64 b2 = lz_ld64(src + ip - 2u); table[lz_hash5<HASHLOG>(b2)] = lz_entry<POSBITS>(ip - 2u, (u32)b2); }   // fast.h:146
+        lz_lds_sync();
         special = 1u;                                                    // fast.h:149-165 == slot 0 of the next round
     }
 tail:
@@ -322,12 +352,15 @@ LZ_DEV u32 lz_write_subblock_huf(const u8* in, u32 n, u8* op, LzStreams& st, u32
 
 // ---- one API block: reference Lizard_compress_extState on a zeroed state (lizard_compress.c:583) ----
 // dst must have room for Lizard_compressBound(n) bytes. Returns the compressed size (uniform).
-// `tag` must provide max(2^TAGLOG bytes, HUF ? 4*LZ_HUF_WS_WORDS : 0) bytes of 4-byte aligned LDS.
+// AUX: fast parser -> POSBITS of the table entries (22: blocks <= 4 MiB, 32: any size);
+//      priceFast   -> TAGLOG of the round tag array.
+// `ws`: 4-byte aligned LDS: priceFast needs 2^TAGLOG bytes, the Huffman stage 4*LZ_HUF_WS_WORDS bytes
+//       (the two never live together); the fast parser without Huffman needs none (may be null).
 // PARSER: 0 = fastSmall/fast + fastLZ4 codewords, 1 = priceFast + LIZv1 codewords.
 #define LZ_PARSER_FAST      0
 #define LZ_PARSER_PRICEFAST 1
-template <int PARSER, int HASHLOG, int TAGLOG, bool HUF>
-LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, u32* table, u8* tag, u8* scratch)
+template <int PARSER, int HASHLOG, int AUX, bool HUF>
+LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, u32* table, u8* ws, u8* scratch)
 {
     const u32 lane = lz_lane();
     LzStreams st;
@@ -340,10 +373,10 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, u32* tabl
     for (u32 pos = 0; pos < n; ) {                            // lizard_compress.c:494
         const u32 part = (n - pos) < LZ_SUBBLOCK ? (n - pos) : LZ_SUBBLOCK;
         st.nlit = st.nflags = st.noff16 = st.noff24 = 0;      // Lizard_initBlock, :130-138
-        if (PARSER == LZ_PARSER_FAST) lz_parse_fast<HASHLOG, TAGLOG>(src, pos, pos + part, table, tag, st);
-        else                          lz_parse_pricefast<HASHLOG, TAGLOG>(src, pos, pos + part, table, tag, st);
-        if (HUF) op += lz_write_subblock_huf(src + pos, part, dst + op, st, (u32*)tag);
-        else     op += lz_write_subblock_raw_streams(src + pos, part, dst + op, st);
+        if constexpr (PARSER == LZ_PARSER_FAST) lz_parse_fast<HASHLOG, AUX>(src, pos, pos + part, table, st);
+        else                                    lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, table, ws, st);
+        if constexpr (HUF) op += lz_write_subblock_huf(src + pos, part, dst + op, st, (u32*)ws);
+        else               op += lz_write_subblock_raw_streams(src + pos, part, dst + op, st);
         lz_wave_sync();                                       // scratch is reused by the next sub-block
         pos += part;
     }

@@ -61,6 +61,17 @@ LZ_DEV u32 lz_claim_index(u32* counter)
     return lz_readlane(old, 0);
 }
 
+// Ordering point for LDS traffic only, between the lanes of ONE wave.  DS instructions of a wave execute
+// in issue order, so the hardware needs nothing; the wavefront-scope fences only stop the compiler from
+// reordering LDS accesses across the point or forwarding a lane's own store to its later load.  Unlike
+// lz_wave_sync() this does not drain vmcnt, so pending global stores (stream output) stay in flight.
+LZ_DEV void lz_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 LZ_DEV u32 lz_ctz64(u64 m) { return (u32)__builtin_ctzll(m); }         // m != 0
 LZ_DEV u32 lz_clz64(u64 m) { return (u32)__builtin_clzll(m); }         // m != 0
 LZ_DEV u32 lz_popc64(u64 m) { return (u32)__builtin_popcountll(m); }
