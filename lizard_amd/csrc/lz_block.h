@@ -171,6 +171,28 @@ template <int POSBITS> LZ_DEV u32 lz_entry_pos(u32 e)
     else return e & ((1u << POSBITS) - 1u);
 }
 
+// Position handled by `slot` of the current run.  A run that follows a match ("special") spends its first
+// two slots on the reference's post-match steps: slot 0 = put(ip-2) only (fast.h:146), slot 1 = the
+// probe of ip itself (fast.h:149-165; identical to a search visit that cannot extend backwards because
+// anchor == ip), slots >= 2 = visits 0.. of the search run starting at ip+1 (fast.h:184).
+LZ_DEV void lz_slot_pos(u32 ip, u32 special, u32 slot, u32 mflimit, u32& p, bool& valid, bool& putOnly)
+{
+    putOnly = false;
+    if (special && slot < 2u) { p = ip - 2u + 2u * slot; valid = true; putOnly = slot == 0; }   // ip <= mflimit guaranteed (fast.h:143)
+    else {
+        const u32 v = slot - 2u * special;
+        p = ip + special + lz_visit_off(v);
+        valid = p + lz_visit_step(v) <= mflimit;                         // fast.h:84, tested before the probe
+    }
+}
+
+// Memory-latency structure of a round (the parse is latency-bound: ~70 % of wave time is s_waitcnt):
+//   * the 8 source bytes of every lane are loaded ONE ROUND AHEAD (nextBytes), for the slots the run
+//     will reach if the current round finds no match, and right after a match for the first round of
+//     the next run, before the sequence is encoded — so encoding overlaps them;
+//   * lanes whose candidate survives the check bits fetch, in one batch, everything the winner needs:
+//     16 bytes forward at candidate and position (resolves match lengths < 16 without another trip)
+//     and 8 bytes backward (resolves backward extensions < 8).
 template <int HASHLOG, int POSBITS>
 LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, u32* table, LzStreams& st)
 {
@@ -188,22 +210,19 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, u32* table, LzStreams& st
 
     u32 ip = S + 1u;        // uniform: run start, or (special==1) the post-match probe position
     u32 special = 0;        // uniform
+    u64 nextBytes = 0;      // source bytes of my slot in the coming round, loaded ahead
+    bool hasNext = false;   // uniform
     for (;;) {
-        // ---------------- search: rounds of 64 visits until a lane accepts ----------------
-        u32 v0 = 0;         // uniform: visits consumed by earlier rounds of this run (incl. the special one)
-        u32 P = 0, M = 0;   // uniform: winner position and its candidate
+        // ---------------- search: rounds of 64 slots until a lane accepts ----------------
+        u32 v0 = 0;         // uniform: slots consumed by earlier rounds of this run
+        u32 P = 0, M = 0, ml = 0, back = 0;   // uniform: winner position, candidate, lengths
         for (;;) {
-            const u32 slot = v0 + lane;                 // slot 0 of a special run is the probe of `ip` itself
-            u32 p; bool valid;
-            if (special && slot == 0) { p = ip; valid = true; }          // caller guarantees ip <= mflimit (fast.h:143)
-            else {
-                const u32 v = slot - special;
-                p = ip + special + lz_visit_off(v);
-                valid = p + lz_visit_step(v) <= mflimit;                 // fast.h:84, tested before the probe
-            }
+            u32 p; bool valid, putOnly;
+            lz_slot_pos(ip, special, v0 + lane, mflimit, p, valid, putOnly);
             u32 h = 0, e = LZ_EMPTY, first4 = 0, mine = 0;
+            u64 bytes = 0;
             if (valid) {
-                const u64 bytes = lz_ld64(src + p);
+                bytes = hasNext ? nextBytes : lz_ld64(src + p);
                 first4 = (u32)bytes;
                 h = lz_hash5<HASHLOG>(bytes);
                 mine = lz_entry<POSBITS>(p, first4);
@@ -212,10 +231,10 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, u32* table, LzStreams& st
             lz_converge();                                               // every lane has read before any lane puts
             if (valid) table[h] = mine;                                  // speculative put (fast.h:88); undone below if needed
             lz_lds_sync();
-            // two visits of this round on one slot: the later must see the earlier's put, in visit order
+            // two slots of this round on one table slot: the later must see the earlier's put, in order
             const bool lost = valid && table[h] != mine;
             u64 pend = lz_ballot(lost);                                  // uniform
-            u64 grp = laneBit;                                           // lanes of this round on my slot
+            u64 grp = laneBit;                                           // lanes of this round on my table slot
             const u32 eOld = e;
             if (pend) {
                 while (pend) {
@@ -231,45 +250,78 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, u32* table, LzStreams& st
                 const u32 ej = lz_shfl(mine, j);
                 if (prev) e = ej;
             }
-            // accept test, fast.h:90-97 (check bits first: they decide whether the 4 bytes are fetched at all)
-            bool ok = false;
-            {
-                const u32 ep = lz_entry_pos<POSBITS>(e);
-                const bool chk = POSBITS >= 32 || ((e ^ mine) >> (POSBITS & 31)) == 0;
-                if (valid && chk && ep >= lowPos && ep < p && p - ep <= LZ_MAX_DIST_LZ4 && p - ep >= LZ_MIN_OFFSET)
-                    ok = lz_ld32(src + ep) == first4;
+            // accept test, fast.h:90-97 (check bits first: they decide whether any bytes are fetched)
+            const u32 ep = lz_entry_pos<POSBITS>(e);
+            bool cand = valid && !putOnly && ep >= lowPos && ep < p && p - ep <= LZ_MAX_DIST_LZ4 && p - ep >= LZ_MIN_OFFSET;
+            if (POSBITS < 32) cand = cand && ((e ^ mine) >> (POSBITS & 31)) == 0;
+            u64 cA = 0, cB = 0, pB = 0, cZ = 0, pZ = 0;
+            const bool haveBack = cand && ep >= 8u;                      // then p >= 16 as well
+            if (cand) {
+                cA = lz_ld64(src + ep); cB = lz_ld64(src + ep + 8u); pB = lz_ld64(src + p + 8u);   // p + 16 <= E - 5
+                if (haveBack) { cZ = lz_ld64(src + ep - 8u); pZ = lz_ld64(src + p - 8u); }
             }
+            // source bytes for the next round of this run (used only if no lane accepts)
+            u64 ahead = 0;
+            {
+                u32 p2; bool valid2, po2;
+                lz_slot_pos(ip, special, v0 + 64u + lane, mflimit, p2, valid2, po2);
+                if (valid2) ahead = lz_ld64(src + p2);
+            }
+            const bool ok = cand && (u32)cA == first4;                   // fast.h:97
             const u64 okMask = lz_ballot(ok);                            // uniform
             const u64 validMask = lz_ballot(valid);                      // uniform, a prefix of lanes
             u32 w = 0;
             u64 commit = validMask;
             if (okMask) { w = lz_ctz64(okMask); commit = validMask & (~0ull >> (63u - w)); }
-            // settle the slots: visits after the winner never happened (the reference stopped there)
+            // settle the table slots: slots after the winner never happened (the reference stopped there)
             if (valid) {
                 if (grp == laneBit) { if (!(commit & laneBit)) table[h] = eOld; }          // undo my put
                 else {
                     const u64 c = grp & commit;
-                    if (c) { if (lane == 63u - lz_clz64(c)) table[h] = mine; }             // last committed visit wins
+                    if (c) { if (lane == 63u - lz_clz64(c)) table[h] = mine; }             // last committed slot wins
                     else if (lane == lz_ctz64(grp)) table[h] = eOld;                       // whole group undone
                 }
             }
             lz_lds_sync();
-            if (okMask) { P = lz_readlane(p, w); M = lz_readlane(lz_entry_pos<POSBITS>(e), w); break; }
+            if (okMask) {
+                // lengths from the batch: common prefix < 16 and common suffix < 8 are exact, else 0xFF = unresolved
+                u32 fwd = 0xFFu, bwd = 0xFFu;
+                {
+                    const u64 x = bytes ^ cA, y = pB ^ cB;
+                    if (x) fwd = lz_ctz64(x) >> 3; else if (y) fwd = 8u + (lz_ctz64(y) >> 3);
+                    const u64 z = pZ ^ cZ;
+                    if (haveBack && z) bwd = lz_clz64(z) >> 3;
+                }
+                P = lz_readlane(p, w); M = lz_readlane(ep, w);
+                ml = lz_readlane(fwd, w); back = lz_readlane(bwd, w);
+                break;
+            }
             if (validMask != ~0ull) goto tail;                           // ran into mflimit without a match
-            v0 += 64u;
+            v0 += 64u; nextBytes = ahead; hasNext = true;
         }
-        // ---------------- extend, encode ----------------
+        // ---------------- extend ----------------
+        if (ml != 0xFFu) { const u32 room = matchlimit - P; ml = ml < room ? ml : room; }        // fast.h:100: count stops at matchlimit
+        else ml = 4u + lz_count_fwd(src, P + 4u, M + 4u, matchlimit);
         {
-            u32 ml = 4u + lz_count_fwd(src, P + 4u, M + 4u, matchlimit); // fast.h:100
-            const u32 back = lz_count_back(src, P, M, anchor);           // fast.h:102 (0 when P == anchor)
-            P -= back; M -= back; ml += back;
-            lz_emit_lz4(src, anchor, P, ml, M, st);                      // fast.h:138
-            ip = P + ml; anchor = ip;
+            const u32 roomP = P - anchor, roomB = roomP < M ? roomP : M;                         // fast.h:102 bounds
+            if (back != 0xFFu) back = back < roomB ? back : roomB;
+            else back = lz_count_back(src, P, M, anchor);
         }
-        if (ip > mflimit) goto tail;                                     // fast.h:143
-        if (lane == 0) { const u64 b2 = lz_ld64(src + ip - 2u); table[lz_hash5<HASHLOG>(b2)] = lz_entry<POSBITS>(ip - 2u, (u32)b2); }   // fast.h:146
-        lz_lds_sync();
-        special = 1u;                                                    // fast.h:149-165 == slot 0 of the next round
+        P -= back; M -= back; ml += back;
+        ip = P + ml;
+        if (ip > mflimit) {                                              // fast.h:143
+            lz_emit_lz4(src, anchor, P, ml, M, st); anchor = ip;
+            goto tail;
+        }
+        // first round of the next run: fetch its source bytes now, so that encoding overlaps the loads
+        special = 1u; hasNext = true;
+        {
+            u32 p2; bool valid2, po2;
+            lz_slot_pos(ip, 1u, lane, mflimit, p2, valid2, po2);
+            nextBytes = valid2 ? lz_ld64(src + p2) : 0ull;
+        }
+        lz_emit_lz4(src, anchor, P, ml, M, st);                          // fast.h:138
+        anchor = ip;
     }
 tail:
     lz_emit_last_literals(src, anchor, E, st);                           // fast.h:187-190
