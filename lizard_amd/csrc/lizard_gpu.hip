@@ -26,10 +26,13 @@ struct LzBatch {
 // level 10/30 parser: the 2^12-entry hash table (16 KiB) is the only LDS the parser needs -> 10 waves
 // per CU; level 30 adds the Huffman stage's workspace.  POSBITS 22 (10 check bits per entry) for
 // blocks <= 4 MiB, 32 for larger ones.
+#ifndef LZ_EXP_HASHLOG
+#define LZ_EXP_HASHLOG 12     // experiment knob (timing only: any other value changes the output)
+#endif
 template <bool HUF, int POSBITS>
 __global__ __launch_bounds__(64) void lz_fast12_kernel(LzBatch a)
 {
-    __shared__ u32 table[1u << 12];
+    __shared__ u32 table[1u << LZ_EXP_HASHLOG];
     __shared__ u32 tagws[HUF ? LZ_HUF_WS_WORDS : 1u];
     u8* tag = (u8*)tagws;
     u8* scratch = a.scratch + (u64)blockIdx.x * LZ_SCRATCH_BYTES;
@@ -38,7 +41,7 @@ __global__ __launch_bounds__(64) void lz_fast12_kernel(LzBatch a)
         const u32 b = lz_claim_index(a.counter);
         if (b >= a.nBlocks) break;
         const u32 n = (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
-        const u32 c = lz_compress_block<LZ_PARSER_FAST, 12, POSBITS, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
+        const u32 c = lz_compress_block<LZ_PARSER_FAST, LZ_EXP_HASHLOG, POSBITS, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
                                                      a.level, table, tag, scratch);
         if (lz_lane() == 0) a.sizes[b] = c;
         lz_converge();
@@ -132,6 +135,9 @@ int ctx_init_locked()
     g_ctx.wavesPf = g_ctx.cus * perCuPf;
     g_ctx.wavesPfHuf = g_ctx.cus * perCuPfHuf;
     LZ_HIP(hipMalloc((void**)&g_ctx.scratch, (size_t)g_ctx.waves * LZ_SCRATCH_BYTES));
+#ifdef LZ_PROFILE
+    LZ_HIP(hipMemset(g_ctx.scratch, 0, (size_t)g_ctx.waves * LZ_SCRATCH_BYTES));
+#endif
     LZ_HIP(hipMalloc((void**)&g_ctx.counter, 64));
     LZ_HIP(hipEventCreate(&g_ctx.ev0));
     LZ_HIP(hipEventCreate(&g_ctx.ev1));
@@ -322,6 +328,27 @@ int LizardGPU_datagen_device(void* d_dst, size_t nBlocks, size_t blockSize, doub
     pthread_mutex_unlock(&g_mu);
     return rc;
 }
+
+#ifdef LZ_PROFILE
+// Profile builds only: sum of the per-wave phase clocks since the last call (scratch slot heads), then reset.
+int LizardGPU_profileDump(unsigned long long out[8])
+{
+    pthread_mutex_lock(&g_mu);
+    int rc = ctx_init_locked();
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    if (!rc) {
+        (void)hipDeviceSynchronize();
+        for (int w = 0; w < g_ctx.waves; w++) {
+            unsigned long long v[8];
+            if (hipMemcpy(v, g_ctx.scratch + (size_t)(w + 1) * LZ_SCRATCH_BYTES - 64, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) { rc = -LIZARDGPU_ERR_HIP; break; }
+            for (int k = 0; k < 8; k++) out[k] += v[k];
+            (void)hipMemset(g_ctx.scratch + (size_t)(w + 1) * LZ_SCRATCH_BYTES - 64, 0, sizeof v);
+        }
+    }
+    pthread_mutex_unlock(&g_mu);
+    return rc;
+}
+#endif
 
 float LizardGPU_lastKernelMs(void)
 {

@@ -43,7 +43,23 @@
 struct LzStreams {
     u8* lit;    u8* flags;  u8* off16;  u8* off24;      // scratch bases (each LZ_SUBBLOCK_PAD bytes)
     u32 nlit;   u32 nflags; u32 noff16; u32 noff24;     // uniform byte counts of the current sub-block
+    // fastLZ4 record whose literal loads are still in flight (stored by the NEXT lz_emit_lz4 / lz_emit_flush,
+    // so that no sequence waits for its own literal bytes): per lane bytes i and i+64 of the record
+    u32 pendLd0, pendLd1, pendCv0, pendCv1;             // loaded literal / computed byte, per lane
+    u32 pendLit;                                        // per lane: bit0/bit1 = byte i / i+64 is a literal
+    u32 pendN;                                          // uniform: record bytes pending (<= 128), 0 = none
+    u32 pendAt;                                         // uniform: offset of the record in the literals stream
+#ifdef LZ_PROFILE
+    u64 prof_last; u64 prof[8];                         // shader-clock deltas per phase (profile builds only)
+#endif
 };
+// Phase profiling exists only in -DLZ_PROFILE builds of the library (lizard_amd/variants/prof), never in
+// the shipped liblizard_amd.so: LZ_PROF(st, k) adds the shader clocks since the previous mark to slot k.
+#ifdef LZ_PROFILE
+#define LZ_PROF(st, k) do { const u64 t_ = __builtin_readcyclecounter(); (st).prof[k] += t_ - (st).prof_last; (st).prof_last = t_; } while (0)
+#else
+#define LZ_PROF(st, k) ((void)0)
+#endif
 #define LZ_SCRATCH_BYTES (4u * LZ_SUBBLOCK_PAD)
 
 LZ_DEV void lz_streams_bind(LzStreams& st, u8* scratch)
@@ -51,6 +67,7 @@ LZ_DEV void lz_streams_bind(LzStreams& st, u8* scratch)
     st.lit = scratch; st.flags = scratch + LZ_SUBBLOCK_PAD;
     st.off16 = scratch + 2 * LZ_SUBBLOCK_PAD; st.off24 = scratch + 3 * LZ_SUBBLOCK_PAD;
     st.nlit = st.nflags = st.noff16 = st.noff24 = 0;
+    st.pendN = 0; st.pendAt = 0; st.pendLd0 = st.pendLd1 = st.pendCv0 = st.pendCv1 = st.pendLit = 0;
 }
 
 // 64-bit-build hash of the reference: hash5 over an 8-byte little-endian read
@@ -69,17 +86,25 @@ LZ_DEV u32 lz_visit_off(u32 v)
 LZ_DEV u32 lz_visit_step(u32 v) { return v == 0 ? 1u : (63u + v) >> 6; }
 
 // Common-prefix length of src[a..] and src[b..] (b < a) with a+i < limit — reference
-// lib/lizard_common.h:475-490 (its 8/4/2/1-byte stepping is unobservable). 64 bytes per round.
+// lib/lizard_common.h:475-490 (its 8/4/2/1-byte stepping is unobservable). 512 bytes per round: lane i
+// compares the 8 bytes at offset 8i.  Reads up to 7 bytes past `limit`; every caller's limit is at
+// least 16 bytes before the end of the block (matchlimit = E - 16).
 LZ_DEV u32 lz_count_fwd(const u8* src, u32 a, u32 b, u32 limit)
 {
     const u32 lane = lz_lane();
     u32 n = 0;                                              // uniform
     for (;;) {
-        const u32 i = n + lane;
-        const bool eq = (a + i < limit) && (src[a + i] == src[b + i]);
-        const u64 ne = lz_ballot(!eq);
-        if (ne) return n + lz_ctz64(ne);
-        n += 64;
+        const u32 i = n + 8u * lane;
+        u32 c = 0;                                          // equal bytes in my 8, clamped to the limit
+        if (a + i < limit) {
+            const u64 x = lz_ld64(src + a + i) ^ lz_ld64(src + b + i);
+            const u32 room = limit - (a + i);
+            c = x ? lz_ctz64(x) >> 3 : 8u;
+            c = c < room ? c : room;
+        }
+        const u64 stop = lz_ballot(c < 8u);
+        if (stop) { const u32 f = lz_ctz64(stop); return n + 8u * f + lz_readlane(c, f); }
+        n += 512u;
     }
 }
 
@@ -117,20 +142,53 @@ LZ_DEV void lz_len_ext(bool present, u32 v, u32& word, u32& nbytes)
     else                   { word = 255u | (v << 8); nbytes = 4; }
 }
 
+// Store the record left pending by the previous lz_emit_lz4 (its literal loads have long completed).
+LZ_DEV void lz_emit_flush(LzStreams& st)
+{
+    if (st.pendN) {
+        const u32 lane = lz_lane();
+        u8* out = st.lit + st.pendAt;
+        if (lane < st.pendN) out[lane] = (u8)((st.pendLit & 1u) ? st.pendLd0 : st.pendCv0);
+        if (lane + 64u < st.pendN) out[lane + 64u] = (u8)((st.pendLit & 2u) ? st.pendLd1 : st.pendCv1);
+        st.pendN = 0;
+    }
+}
+
 // fastLZ4 sequence (reference lib/lizard_compress_lz4.h:3-71): token -> flags stream; literal-length
-// escape, literals, LE16 offset and match-length escape -> literals stream, as one contiguous record
-// whose bytes are produced 64 at a time, one per lane.
+// escape, literals, LE16 offset and match-length escape -> literals stream, as one contiguous record.
+// Each lane produces bytes i and i+64 of the record: the literal loads are only ISSUED here and the
+// first 128 bytes are stored by the next emit/flush; a longer record stores its remainder at once.
 LZ_DEV void lz_emit_lz4(const u8* src, u32 anchor, u32 P, u32 ml, u32 M, LzStreams& st)
 {
     const u32 lane = lz_lane();
+    lz_emit_flush(st);
     const u32 L = P - anchor, off = P - M, mlc = ml - 4u;
     u32 extLw, extLn, extMw, extMn;
     lz_len_ext(L >= 15u, L - 15u, extLw, extLn);
     lz_len_ext(mlc >= 15u, mlc - 15u, extMw, extMn);
     const u32 token = (L >= 15u ? 15u : L) | ((mlc >= 15u ? 15u : mlc) << 4);
     const u32 oOff = extLn + L, oExtM = oOff + 2u, R = oExtM + extMn;
+    u32 lit = 0, ld0 = 0, ld1 = 0, cv0 = 0, cv1 = 0;
+    {
+        const u32 i = lane;
+        if (i < extLn)       cv0 = extLw >> (8u * i);
+        else if (i < oOff)   { lit |= 1u; ld0 = src[anchor + (i - extLn)]; }
+        else if (i < oExtM)  cv0 = off >> (8u * (i - oOff));
+        else                 cv0 = extMw >> (8u * (i - oExtM));
+    }
+    {
+        const u32 i = lane + 64u;
+        if (i < R) {
+            if (i < extLn)       cv1 = extLw >> (8u * i);
+            else if (i < oOff)   { lit |= 2u; ld1 = src[anchor + (i - extLn)]; }
+            else if (i < oExtM)  cv1 = off >> (8u * (i - oOff));
+            else                 cv1 = extMw >> (8u * (i - oExtM));
+        }
+    }
+    st.pendLd0 = ld0; st.pendLd1 = ld1; st.pendCv0 = cv0; st.pendCv1 = cv1; st.pendLit = lit;
+    st.pendN = R < 128u ? R : 128u; st.pendAt = st.nlit;
     u8* out = st.lit + st.nlit;
-    for (u32 i = lane; i < R; i += 64u) {
+    for (u32 i = 128u + lane; i < R; i += 64u) {                 // rare: literal runs beyond ~120 bytes
         u32 b;
         if (i < extLn)       b = extLw >> (8u * i);
         else if (i < oOff)   b = src[anchor + (i - extLn)];
@@ -217,8 +275,15 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, u32* table, LzStreams& st
         u32 v0 = 0;         // uniform: slots consumed by earlier rounds of this run
         u32 P = 0, M = 0, ml = 0, back = 0;   // uniform: winner position, candidate, lengths
         for (;;) {
+            LZ_PROF(st, 3);                                              // (loop glue / encode tail)
             u32 p; bool valid, putOnly;
             lz_slot_pos(ip, special, v0 + lane, mflimit, p, valid, putOnly);
+            u32 pAhead;                                                  // my slot's position in the next round of this run
+            {
+                bool valid2, po2;
+                lz_slot_pos(ip, special, v0 + 64u + lane, mflimit, pAhead, valid2, po2);
+                if (!valid2) pAhead = S;                                 // any readable address
+            }
             u32 h = 0, e = LZ_EMPTY, first4 = 0, mine = 0;
             u64 bytes = 0;
             if (valid) {
@@ -256,18 +321,26 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, u32* table, LzStreams& st
             if (POSBITS < 32) cand = cand && ((e ^ mine) >> (POSBITS & 31)) == 0;
             u64 cA = 0, cB = 0, pB = 0, cZ = 0, pZ = 0;
             const bool haveBack = cand && ep >= 8u;                      // then p >= 16 as well
-            if (cand) {
-                cA = lz_ld64(src + ep); cB = lz_ld64(src + ep + 8u); pB = lz_ld64(src + p + 8u);   // p + 16 <= E - 5
-                if (haveBack) { cZ = lz_ld64(src + ep - 8u); pZ = lz_ld64(src + p - 8u); }
+            if (cand) {                                                  // one batch, straight-line: p + 16 <= E - 5
+                const u32 zb = haveBack ? 8u : 0u;
+                cA = lz_ld64(src + ep); cB = lz_ld64(src + ep + 8u); pB = lz_ld64(src + p + 8u);
+                cZ = lz_ld64(src + ep - zb); pZ = lz_ld64(src + p - zb);
             }
-            // source bytes for the next round of this run (used only if no lane accepts)
-            u64 ahead = 0;
-            {
-                u32 p2; bool valid2, po2;
-                lz_slot_pos(ip, special, v0 + 64u + lane, mflimit, p2, valid2, po2);
-                if (valid2) ahead = lz_ld64(src + p2);
-            }
+            // source bytes for the next round of this run (consumed only if no lane accepts).  Always
+            // issued and assigned unconditionally: no select forces the load to complete inside this
+            // round and the vmcnt arithmetic of the batch above stays exact.
+            nextBytes = lz_ld64(src + pAhead);
+            hasNext = true;
+            LZ_PROF(st, 0);                                              // round part A: bytes wait, hash, LDS, filter, loads issued
             const bool ok = cand && (u32)cA == first4;                   // fast.h:97
+            // lengths from the batch: common prefix < 16 and common suffix < 8 are exact, 0xFF = unresolved
+            u32 fwd = 0xFFu, bwd = 0xFFu;
+            {
+                const u64 x = bytes ^ cA, y = pB ^ cB, z = pZ ^ cZ;
+                if (x) fwd = lz_ctz64(x) >> 3; else if (y) fwd = 8u + (lz_ctz64(y) >> 3);
+                if (haveBack && z) bwd = lz_clz64(z) >> 3;
+            }
+            lz_pin(fwd); lz_pin(bwd);                                    // computed here, under this batch's counted wait
             const u64 okMask = lz_ballot(ok);                            // uniform
             const u64 validMask = lz_ballot(valid);                      // uniform, a prefix of lanes
             u32 w = 0;
@@ -283,21 +356,14 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, u32* table, LzStreams& st
                 }
             }
             lz_lds_sync();
+            LZ_PROF(st, 1);                                              // round part B: candidate wait, ballots, slot settle
             if (okMask) {
-                // lengths from the batch: common prefix < 16 and common suffix < 8 are exact, else 0xFF = unresolved
-                u32 fwd = 0xFFu, bwd = 0xFFu;
-                {
-                    const u64 x = bytes ^ cA, y = pB ^ cB;
-                    if (x) fwd = lz_ctz64(x) >> 3; else if (y) fwd = 8u + (lz_ctz64(y) >> 3);
-                    const u64 z = pZ ^ cZ;
-                    if (haveBack && z) bwd = lz_clz64(z) >> 3;
-                }
                 P = lz_readlane(p, w); M = lz_readlane(ep, w);
                 ml = lz_readlane(fwd, w); back = lz_readlane(bwd, w);
                 break;
             }
             if (validMask != ~0ull) goto tail;                           // ran into mflimit without a match
-            v0 += 64u; nextBytes = ahead; hasNext = true;
+            v0 += 64u;
         }
         // ---------------- extend ----------------
         if (ml != 0xFFu) { const u32 room = matchlimit - P; ml = ml < room ? ml : room; }        // fast.h:100: count stops at matchlimit
@@ -309,6 +375,7 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, u32* table, LzStreams& st
         }
         P -= back; M -= back; ml += back;
         ip = P + ml;
+        LZ_PROF(st, 2);                                                  // extension
         if (ip > mflimit) {                                              // fast.h:143
             lz_emit_lz4(src, anchor, P, ml, M, st); anchor = ip;
             goto tail;
@@ -324,7 +391,10 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, u32* table, LzStreams& st
         anchor = ip;
     }
 tail:
+    LZ_PROF(st, 3);
+    lz_emit_flush(st);
     lz_emit_last_literals(src, anchor, E, st);                           // fast.h:187-190
+    LZ_PROF(st, 4);                                                      // trailing literals
 }
 
 LZ_DEV void lz_st24(u8* p, u32 v) { p[0] = (u8)v; p[1] = (u8)(v >> 8); p[2] = (u8)(v >> 16); }
@@ -417,8 +487,13 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, u32* tabl
     const u32 lane = lz_lane();
     LzStreams st;
     lz_streams_bind(st, scratch);
+#ifdef LZ_PROFILE
+    st.prof_last = __builtin_readcyclecounter();
+    for (int k = 0; k < 8; k++) st.prof[k] = 0;
+#endif
     for (u32 i = lane; i < (1u << HASHLOG); i += 64u) table[i] = LZ_EMPTY;
     lz_wave_sync();
+    LZ_PROF(st, 6);                                           // table init
     if (lane == 0) dst[0] = (u8)level;                        // lizard_compress.c:488
     lz_converge();
     u32 op = 1u;                                              // uniform
@@ -430,7 +505,12 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, u32* tabl
         if constexpr (HUF) op += lz_write_subblock_huf(src + pos, part, dst + op, st, (u32*)ws);
         else               op += lz_write_subblock_raw_streams(src + pos, part, dst + op, st);
         lz_wave_sync();                                       // scratch is reused by the next sub-block
+        LZ_PROF(st, 5);                                       // container: stream copies / Huffman
         pos += part;
     }
+#ifdef LZ_PROFILE
+    if (lane == 0) { u64* pr = (u64*)(scratch + LZ_SCRATCH_BYTES - 64u); for (int k = 0; k < 8; k++) pr[k] += st.prof[k]; }   // per-wave totals at the tail of its scratch slot
+    lz_converge();
+#endif
     return op;
 }

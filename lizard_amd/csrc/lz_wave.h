@@ -72,6 +72,11 @@ LZ_DEV void lz_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Pin a per-lane value: it must be computed HERE (the optimiser may not sink its computation into a
+// later conditional block).  Used to keep arithmetic on just-loaded data next to the counted
+// s_waitcnt of its own load batch instead of behind a later, conservative vmcnt(0).
+LZ_DEV void lz_pin(u32& x) { asm volatile("" : "+v"(x)); }
+
 LZ_DEV u32 lz_ctz64(u64 m) { return (u32)__builtin_ctzll(m); }         // m != 0
 LZ_DEV u32 lz_clz64(u64 m) { return (u32)__builtin_clzll(m); }         // m != 0
 LZ_DEV u32 lz_popc64(u64 m) { return (u32)__builtin_popcountll(m); }

@@ -102,6 +102,7 @@ LZ_DEV u32 lz_shfl(u32 v, u32 srcLane)
 LZ_DEV void lz_wave_sync() { lzemu::park(lzemu::OP_SYNC); }
 
 LZ_DEV void lz_lds_sync() { lzemu::park(lzemu::OP_SYNC); }
+LZ_DEV void lz_pin(u32& x) { (void)x; }
 LZ_DEV void lz_converge() { lzemu::park(lzemu::OP_SYNC); }   // all lanes must arrive together
 
 LZ_DEV u32 lz_ctz64(u64 m) { return (u32)__builtin_ctzll(m); }

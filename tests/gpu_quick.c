@@ -6,6 +6,8 @@
  *   build: gcc -O2 tests/gpu_quick.c -o tests/gpu_quick -Iinclude -Ioracle -Llizard_amd -llizard_amd \
  *              -Loracle -llizard_oracle -lpthread -Wl,-rpath,'$ORIGIN/../lizard_amd:$ORIGIN/../oracle'
  */
+#define _GNU_SOURCE
+#include <dlfcn.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -112,6 +114,15 @@ int main(int argc, char** argv)
             if (bad) fails++;
             printf("%-28s %s  kernel %.2f ms  %.2f GB/s input  ratio %.3f\n", name, bad ? "FAIL" : "ok", ms,
                    (double)nb * bs / (ms * 1e-3) / 1e9, tot ? (double)nb * bs / tot : 0.0);
+            {   /* instrumented library variant only (LD_LIBRARY_PATH=lizard_amd/variants/prof) */
+                int (*dump)(unsigned long long*) = (int (*)(unsigned long long*))dlsym(RTLD_DEFAULT, "LizardGPU_profileDump");
+                unsigned long long pr[8];
+                if (dump && dump(pr) == 0) {
+                    static const char* nm[8] = { "roundA(bytes,hash,LDS,filter)", "roundB(cand wait,settle)", "extension", "glue+encode", "tail literals", "container", "table init", "-" };
+                    double sum = 0; for (int k = 0; k < 8; k++) sum += (double)pr[k];
+                    for (int k = 0; k < 7; k++) printf("    prof %-32s %6.2f %%  %.3g clk\n", nm[k], 100.0 * pr[k] / sum, (double)pr[k]);
+                }
+            }
             fflush(stdout);
             free(out); free(cs);
         }
