@@ -23,16 +23,15 @@ struct LzBatch {
     u8* scratch;    u32* counter;
 };
 
-// level 10/30 parser: the 2^12-entry hash table (16 KiB) is the only LDS the parser needs -> 10 waves
-// per CU; level 30 adds the Huffman stage's workspace.  POSBITS 22 (10 check bits per entry) for
-// blocks <= 4 MiB, 32 for larger ones.
+// level 10/30 parser: the 2^12-slot hash table (24-bit slots, 12 KiB) is the only LDS the parser needs
+// -> 13 waves per CU; level 30 adds the Huffman stage's workspace.
 #ifndef LZ_EXP_HASHLOG
 #define LZ_EXP_HASHLOG 12     // experiment knob (timing only: any other value changes the output)
 #endif
-template <bool HUF, int POSBITS>
+template <bool HUF>
 __global__ __launch_bounds__(64) void lz_fast12_kernel(LzBatch a)
 {
-    __shared__ u32 table[1u << LZ_EXP_HASHLOG];
+    __shared__ u32 table[LZ_TAB_BYTES(LZ_EXP_HASHLOG) / 4u];
     __shared__ u32 tagws[HUF ? LZ_HUF_WS_WORDS : 1u];
     u8* tag = (u8*)tagws;
     u8* scratch = a.scratch + (u64)blockIdx.x * LZ_SCRATCH_BYTES;
@@ -41,7 +40,7 @@ __global__ __launch_bounds__(64) void lz_fast12_kernel(LzBatch a)
         const u32 b = lz_claim_index(a.counter);
         if (b >= a.nBlocks) break;
         const u32 n = (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
-        const u32 c = lz_compress_block<LZ_PARSER_FAST, LZ_EXP_HASHLOG, POSBITS, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
+        const u32 c = lz_compress_block<LZ_PARSER_FAST, LZ_EXP_HASHLOG, 0, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
                                                      a.level, table, tag, scratch);
         if (lz_lane() == 0) a.sizes[b] = c;
         lz_converge();
@@ -120,8 +119,8 @@ int ctx_init_locked()
     hipDeviceProp_t prop;
     LZ_HIP(hipGetDeviceProperties(&prop, g_want_device));
     int perCu = 0, perCuHuf = 0;
-    LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, lz_fast12_kernel<false, 22>, 64, 0));
-    LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuHuf, lz_fast12_kernel<true, 22>, 64, 0));
+    LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, lz_fast12_kernel<false>, 64, 0));
+    LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuHuf, lz_fast12_kernel<true>, 64, 0));
     int perCuPf = 0, perCuPfHuf = 0;
     LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuPf, lz_pricefast14_kernel<false>, 64, 0));
     LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuPfHuf, lz_pricefast14_kernel<true>, 64, 0));
@@ -167,14 +166,8 @@ int launch_locked(const void* d_src, size_t nBlocks, size_t blockSize, size_t la
     LZ_HIP(hipMemsetAsync(g_ctx.counter, 0, 4, stream));
     LZ_HIP(hipEventRecord(g_ctx.ev0, stream));
     switch (lv) {
-    case 10:
-        if (blockSize <= (4u << 20)) hipLaunchKernelGGL((lz_fast12_kernel<false, 22>), dim3(grid), dim3(64), 0, stream, a);
-        else                         hipLaunchKernelGGL((lz_fast12_kernel<false, 32>), dim3(grid), dim3(64), 0, stream, a);
-        break;
-    case 30:
-        if (blockSize <= (4u << 20)) hipLaunchKernelGGL((lz_fast12_kernel<true, 22>), dim3(grid), dim3(64), 0, stream, a);
-        else                         hipLaunchKernelGGL((lz_fast12_kernel<true, 32>), dim3(grid), dim3(64), 0, stream, a);
-        break;
+    case 10: hipLaunchKernelGGL(lz_fast12_kernel<false>, dim3(grid), dim3(64), 0, stream, a); break;
+    case 30: hipLaunchKernelGGL(lz_fast12_kernel<true>, dim3(grid), dim3(64), 0, stream, a); break;
     case 21: hipLaunchKernelGGL(lz_pricefast14_kernel<false>, dim3(grid), dim3(64), 0, stream, a); break;
     default: hipLaunchKernelGGL(lz_pricefast14_kernel<true>, dim3(grid), dim3(64), 0, stream, a); break;
     }

@@ -49,6 +49,7 @@ struct LzStreams {
     u32 pendLit;                                        // per lane: bit0/bit1 = byte i / i+64 is a literal
     u32 pendN;                                          // uniform: record bytes pending (<= 128), 0 = none
     u32 pendAt;                                         // uniform: offset of the record in the literals stream
+    u32 sweepAt;                                        // uniform: position at which the 17-bit table is swept next
 #ifdef LZ_PROFILE
     u64 prof_last; u64 prof[8];                         // shader-clock deltas per phase (profile builds only)
 #endif
@@ -209,24 +210,32 @@ LZ_DEV void lz_emit_last_literals(const u8* src, u32 anchor, u32 E, LzStreams& s
 }
 
 // ---- fastSmall / fast parser over one sub-block [S,E) of the block at `src` ----------------------
-// table: 2^HASHLOG u32 entries, LZ_EMPTY when never written; persists across the sub-blocks of one block
-//        (reference lizard_compress.c:494-540).  LDS for HASHLOG 12.
-// Entry layout (ours; only the parse RESULT is pinned by the reference): low POSBITS bits = position
-// (block-relative), high 32-POSBITS bits = a multiplicative check hash of the 4 bytes at that position.
-// A candidate whose check bits differ from the probing position's cannot pass the reference's 4-byte
-// equality test (fast.h:97), so its bytes are never fetched: most rounds issue no candidate gather at
-// all.  Equal check bits prove nothing; those lanes still load and compare the real 4 bytes.
-// POSBITS 22 serves blocks up to 4 MiB; POSBITS 32 (no check bits) any size.
-template <int POSBITS>
-LZ_DEV u32 lz_entry(u32 p, u32 first4)
+// Hash table (ours; only the parse RESULT is pinned by the reference): 2^HASHLOG slots of 24 bits, kept
+// as a u16 array + a u8 array so that a level-10 table is 12 KiB of LDS (13 waves per CU instead of 10
+// with u32 slots — the parse is latency-bound and throughput scales with resident waves):
+//   bits  0..16  position mod 2^17.  The reference only ever accepts candidates at distance <= 65535
+//                (fast.h:90), so 17 bits are exact as long as no live slot gets older than 2^17-1: a sweep
+//                at least every 2^15 positions re-stamps every slot older than 65535 as "exactly 65536
+//                old" (dead for the reference from then on, and also the encoding of an empty slot).
+//   bits 17..23  check hash of the 4 bytes at that position.  A candidate whose check bits differ from
+//                the probing position's cannot pass the reference's 4-byte equality test (fast.h:97), so
+//                its bytes are never fetched: most rounds issue no candidate gather at all.  Equal check
+//                bits prove nothing; those lanes still load and compare the real bytes.
+struct LzTab { u16* lo; u8* hi; };
+#define LZ_TAB_BYTES(HASHLOG) (3u << (HASHLOG))
+template <int HASHLOG> LZ_DEV LzTab lz_tab_bind(void* mem) { LzTab t; t.lo = (u16*)mem; t.hi = (u8*)mem + (2u << HASHLOG); return t; }
+LZ_DEV u32 lz_tab_entry(u32 p, u32 first4) { return (p & 0x1FFFFu) | ((first4 * 2654435761u) >> 25 << 17); }
+LZ_DEV u32 lz_tab_get(const LzTab& t, u32 h) { return (u32)t.lo[h] | ((u32)t.hi[h] << 16); }
+LZ_DEV void lz_tab_set(const LzTab& t, u32 h, u32 ent) { t.lo[h] = (u16)ent; t.hi[h] = (u8)(ent >> 16); }
+// age of a slot seen from position p (0..131071); usable iff 8 <= age <= 65535 (+ the lowLimit rule)
+LZ_DEV u32 lz_tab_age(u32 p, u32 ent) { return (p - ent) & 0x1FFFFu; }
+// Re-stamp every slot that is dead at position Ps (age >= 65536); with Ps = 0 on a fresh table: all empty.
+template <int HASHLOG>
+LZ_DEV void lz_tab_sweep(const LzTab& t, u32 Ps, bool fresh)
 {
-    if constexpr (POSBITS >= 32) return p;
-    else return p | ((first4 * 2654435761u) >> POSBITS << POSBITS);
-}
-template <int POSBITS> LZ_DEV u32 lz_entry_pos(u32 e)
-{
-    if constexpr (POSBITS >= 32) return e;
-    else return e & ((1u << POSBITS) - 1u);
+    const u32 dead = (Ps + 65536u) & 0x1FFFFu;
+    for (u32 i = lz_lane(); i < (1u << HASHLOG); i += 64u)
+        if (fresh || lz_tab_age(Ps, lz_tab_get(t, i)) >= 65536u) lz_tab_set(t, i, dead);
 }
 
 // Position handled by `slot` of the current run.  A run that follows a match ("special") spends its first
@@ -251,8 +260,8 @@ LZ_DEV void lz_slot_pos(u32 ip, u32 special, u32 slot, u32 mflimit, u32& p, bool
 //   * lanes whose candidate survives the check bits fetch, in one batch, everything the winner needs:
 //     16 bytes forward at candidate and position (resolves match lengths < 16 without another trip)
 //     and 8 bytes backward (resolves backward extensions < 8).
-template <int HASHLOG, int POSBITS>
-LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, u32* table, LzStreams& st)
+template <int HASHLOG>
+LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const LzTab& table, LzStreams& st)
 {
     const u32 lane = lz_lane();
     const u64 laneBit = 1ull << lane;
@@ -263,7 +272,8 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, u32* table, LzStreams& st
     // fast.h:57-58 in block-relative positions: lowLimit is fixed at sub-block entry
     const u32 lowPos = S > LZ_MAX_DIST_LZ4 ? S - LZ_MAX_DIST_LZ4 : 0u;
 
-    if (lane == 0) { const u64 b0 = lz_ld64(src + S); table[lz_hash5<HASHLOG>(b0)] = lz_entry<POSBITS>(S, (u32)b0); }   // fast.h:66
+    if (S >= st.sweepAt) { lz_tab_sweep<HASHLOG>(table, S, false); st.sweepAt = S + 32768u; lz_lds_sync(); }
+    if (lane == 0) { const u64 b0 = lz_ld64(src + S); lz_tab_set(table, lz_hash5<HASHLOG>(b0), lz_tab_entry(S, (u32)b0)); }   // fast.h:66
     lz_lds_sync();
 
     u32 ip = S + 1u;        // uniform: run start, or (special==1) the post-match probe position
@@ -284,20 +294,25 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, u32* table, LzStreams& st
                 lz_slot_pos(ip, special, v0 + 64u + lane, mflimit, pAhead, valid2, po2);
                 if (!valid2) pAhead = S;                                 // any readable address
             }
-            u32 h = 0, e = LZ_EMPTY, first4 = 0, mine = 0;
+            {   // keep every live slot younger than 2^17 positions (see LzTab)
+                const u32 p0 = lz_readlane(p, 0);
+                if (p0 >= st.sweepAt) { lz_tab_sweep<HASHLOG>(table, p0, false); st.sweepAt = p0 + 32768u; lz_lds_sync(); }
+            }
+            u32 h = 0, e = 0, first4 = 0, mine = 0;
             u64 bytes = 0;
             if (valid) {
                 bytes = hasNext ? nextBytes : lz_ld64(src + p);
                 first4 = (u32)bytes;
                 h = lz_hash5<HASHLOG>(bytes);
-                mine = lz_entry<POSBITS>(p, first4);
-                e = table[h];                                            // fast.h:86 (value before this round)
+                mine = lz_tab_entry(p, first4);
+                e = lz_tab_get(table, h);                                // fast.h:86 (value before this round)
             }
             lz_converge();                                               // every lane has read before any lane puts
-            if (valid) table[h] = mine;                                  // speculative put (fast.h:88); undone below if needed
+            if (valid) lz_tab_set(table, h, mine);                       // speculative put (fast.h:88); undone below if needed
             lz_lds_sync();
             // two slots of this round on one table slot: the later must see the earlier's put, in order
-            const bool lost = valid && table[h] != mine;
+            // (positions of one round differ by < 2^16, so the low halves alone tell the writers apart)
+            const bool lost = valid && table.lo[h] != (u16)mine;
             u64 pend = lz_ballot(lost);                                  // uniform
             u64 grp = laneBit;                                           // lanes of this round on my table slot
             const u32 eOld = e;
@@ -316,9 +331,10 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, u32* table, LzStreams& st
                 if (prev) e = ej;
             }
             // accept test, fast.h:90-97 (check bits first: they decide whether any bytes are fetched)
-            const u32 ep = lz_entry_pos<POSBITS>(e);
-            bool cand = valid && !putOnly && ep >= lowPos && ep < p && p - ep <= LZ_MAX_DIST_LZ4 && p - ep >= LZ_MIN_OFFSET;
-            if (POSBITS < 32) cand = cand && ((e ^ mine) >> (POSBITS & 31)) == 0;
+            const u32 age = lz_tab_age(p, e);
+            const u32 ep = p - age;
+            const bool cand = valid && !putOnly && ((e ^ mine) >> 17) == 0 && age >= LZ_MIN_OFFSET && age <= LZ_MAX_DIST_LZ4
+                           && age <= p - lowPos;
             u64 cA = 0, cB = 0, pB = 0, cZ = 0, pZ = 0;
             const bool haveBack = cand && ep >= 8u;                      // then p >= 16 as well
             if (cand) {                                                  // one batch, straight-line: p + 16 <= E - 5
@@ -348,11 +364,11 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, u32* table, LzStreams& st
             if (okMask) { w = lz_ctz64(okMask); commit = validMask & (~0ull >> (63u - w)); }
             // settle the table slots: slots after the winner never happened (the reference stopped there)
             if (valid) {
-                if (grp == laneBit) { if (!(commit & laneBit)) table[h] = eOld; }          // undo my put
+                if (grp == laneBit) { if (!(commit & laneBit)) lz_tab_set(table, h, eOld); }          // undo my put
                 else {
                     const u64 c = grp & commit;
-                    if (c) { if (lane == 63u - lz_clz64(c)) table[h] = mine; }             // last committed slot wins
-                    else if (lane == lz_ctz64(grp)) table[h] = eOld;                       // whole group undone
+                    if (c) { if (lane == 63u - lz_clz64(c)) lz_tab_set(table, h, mine); }             // last committed slot wins
+                    else if (lane == lz_ctz64(grp)) lz_tab_set(table, h, eOld);                       // whole group undone
                 }
             }
             lz_lds_sync();
@@ -474,15 +490,13 @@ LZ_DEV u32 lz_write_subblock_huf(const u8* in, u32 n, u8* op, LzStreams& st, u32
 
 // ---- one API block: reference Lizard_compress_extState on a zeroed state (lizard_compress.c:583) ----
 // dst must have room for Lizard_compressBound(n) bytes. Returns the compressed size (uniform).
-// AUX: fast parser -> POSBITS of the table entries (22: blocks <= 4 MiB, 32: any size);
-//      priceFast   -> TAGLOG of the round tag array.
-// `ws`: 4-byte aligned LDS: priceFast needs 2^TAGLOG bytes, the Huffman stage 4*LZ_HUF_WS_WORDS bytes
-//       (the two never live together); the fast parser without Huffman needs none (may be null).
+// tableMem: fast parser -> LZ_TAB_BYTES(HASHLOG) bytes (24-bit slots, see LzTab); priceFast -> 4 << HASHLOG bytes.
+// AUX:      priceFast only -> TAGLOG of the round tag array.
 // PARSER: 0 = fastSmall/fast + fastLZ4 codewords, 1 = priceFast + LIZv1 codewords.
 #define LZ_PARSER_FAST      0
 #define LZ_PARSER_PRICEFAST 1
 template <int PARSER, int HASHLOG, int AUX, bool HUF>
-LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, u32* table, u8* ws, u8* scratch)
+LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tableMem, u8* ws, u8* scratch)
 {
     const u32 lane = lz_lane();
     LzStreams st;
@@ -491,7 +505,10 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, u32* tabl
     st.prof_last = __builtin_readcyclecounter();
     for (int k = 0; k < 8; k++) st.prof[k] = 0;
 #endif
-    for (u32 i = lane; i < (1u << HASHLOG); i += 64u) table[i] = LZ_EMPTY;
+    LzTab tab = lz_tab_bind<HASHLOG>(tableMem);
+    u32* table = (u32*)tableMem;
+    if constexpr (PARSER == LZ_PARSER_FAST) { lz_tab_sweep<HASHLOG>(tab, 0, true); st.sweepAt = 32768u; }
+    else for (u32 i = lane; i < (1u << HASHLOG); i += 64u) table[i] = LZ_EMPTY;
     lz_wave_sync();
     LZ_PROF(st, 6);                                           // table init
     if (lane == 0) dst[0] = (u8)level;                        // lizard_compress.c:488
@@ -500,7 +517,7 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, u32* tabl
     for (u32 pos = 0; pos < n; ) {                            // lizard_compress.c:494
         const u32 part = (n - pos) < LZ_SUBBLOCK ? (n - pos) : LZ_SUBBLOCK;
         st.nlit = st.nflags = st.noff16 = st.noff24 = 0;      // Lizard_initBlock, :130-138
-        if constexpr (PARSER == LZ_PARSER_FAST) lz_parse_fast<HASHLOG, AUX>(src, pos, pos + part, table, st);
+        if constexpr (PARSER == LZ_PARSER_FAST) lz_parse_fast<HASHLOG>(src, pos, pos + part, tab, st);
         else                                    lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, table, ws, st);
         if constexpr (HUF) op += lz_write_subblock_huf(src + pos, part, dst + op, st, (u32*)ws);
         else               op += lz_write_subblock_raw_streams(src + pos, part, dst + op, st);

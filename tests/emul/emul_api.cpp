@@ -34,16 +34,9 @@ extern "C" int emul_compress_block(const void* src, int n, void* dst, int level,
     memset(a.scratch, 0xCC, LZ_SCRATCH_BYTES);
     static_assert(4 * LZ_HUF_WS_WORDS <= 8192, "emulated LDS workspace too small");
     const bool huf = level >= 30;
-    const int posbits = (seed & 1u) && n <= (4 << 20) ? 22 : 32;     // exercise both table-entry layouts
     switch (base) {
-    case 10:
-        if (posbits == 22) lzemu::run_wave(huf ? entry_block<LZ_PARSER_FAST, 12, 22, true> : entry_block<LZ_PARSER_FAST, 12, 22, false>, &a, seed);
-        else               lzemu::run_wave(huf ? entry_block<LZ_PARSER_FAST, 12, 32, true> : entry_block<LZ_PARSER_FAST, 12, 32, false>, &a, seed);
-        break;
-    case 11:
-        if (posbits == 22) lzemu::run_wave(huf ? entry_block<LZ_PARSER_FAST, 18, 22, true> : entry_block<LZ_PARSER_FAST, 18, 22, false>, &a, seed);
-        else               lzemu::run_wave(huf ? entry_block<LZ_PARSER_FAST, 18, 32, true> : entry_block<LZ_PARSER_FAST, 18, 32, false>, &a, seed);
-        break;
+    case 10: lzemu::run_wave(huf ? entry_block<LZ_PARSER_FAST, 12, 0, true> : entry_block<LZ_PARSER_FAST, 12, 0, false>, &a, seed); break;
+    case 11: lzemu::run_wave(huf ? entry_block<LZ_PARSER_FAST, 18, 0, true> : entry_block<LZ_PARSER_FAST, 18, 0, false>, &a, seed); break;
     case 21: lzemu::run_wave(huf ? entry_block<LZ_PARSER_PRICEFAST, 14, 12, true> : entry_block<LZ_PARSER_PRICEFAST, 14, 12, false>, &a, seed); break;
     default: lzemu::run_wave(huf ? entry_block<LZ_PARSER_PRICEFAST, 18, 12, true> : entry_block<LZ_PARSER_PRICEFAST, 18, 12, false>, &a, seed); break;
     }

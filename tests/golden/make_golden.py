@@ -23,13 +23,13 @@ def main():
     assert ref is not None, "needs /root/reference (build container)"
     dg = util.reference_datagen()
     vec = {"levels": LEVELS, "cases": {}, "frame_style": {}, "p50_64m": {}}
-    for name, data in util.corpus():
+    for name, data in util.corpus() + util.corpus_long():
         entry = {"n": len(data), "input_sha256": util.sha(data), "out": {}}
         for lvl in LEVELS:
             out, r = util.compress_with(ref.Lizard_compress, data, lvl)
             entry["out"][str(lvl)] = {"size": r, "sha256": util.sha(out)}
         # frame-style capacity (lizard_frame.c:461: maxDstSize = srcSize-1): 0 when it does not fit
-        if len(data) > 1:
+        if 1 < len(data) <= 300000:
             fs = {}
             for lvl in (10, 21, 30):
                 out, r = util.compress_with(ref.Lizard_compress, data, lvl, cap=len(data) - 1)

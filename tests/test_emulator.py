@@ -34,6 +34,15 @@ def test_emulated_kernel_vs_golden(level):
         assert len(out) == g["size"] and util.sha(out) == g["sha256"], (name, level)
 
 
+@pytest.mark.parametrize("level", [10, 30, 21])
+def test_emulated_kernel_long_range(level):
+    """Window-edge / position-wrap adversaries and multi-MiB blocks (tests/util.corpus_long)."""
+    for name, data in util.corpus_long():
+        g = GOLDEN["cases"][name]["out"][str(level)]
+        out = emul_compress(data, level, seed=len(name))
+        assert len(out) == g["size"] and util.sha(out) == g["sha256"], (name, level)
+
+
 def test_emulated_kernel_schedule_independent():
     """Output must not depend on the order lanes run between cross-lane ops (LDS store races)."""
     data = dict(util.corpus(small=True))["gen262144_p0.5"]

@@ -54,6 +54,15 @@ def test_corpus_vs_golden_and_oracle(L):
             assert out == util.oracle_compress(data, level), (name, level)
 
 
+def test_long_range_corpus(L):
+    """Window-edge / position-wrap adversaries, sparse long-distance repeats, multi-MiB blocks."""
+    for level in gpu_levels(L):
+        for name, data in util.corpus_long():
+            out, r = gpu_compress(L, data, level)
+            g = GOLDEN["cases"][name]["out"][str(level)]
+            assert r == g["size"] and util.sha(out) == g["sha256"], (name, level)
+
+
 def test_frame_style_capacity(L):
     """maxDstSize = srcSize-1 (reference lib/lizard_frame.c:461): identical bytes when it fits, 0 when not."""
     for level in [l for l in (10, 21, 30) if L.LizardGPU_levelSupported(l)]:

@@ -18,6 +18,7 @@ with open(os.path.join(util.GOLDEN_DIR, "reference_vectors.json")) as f:
     GOLDEN = json.load(f)
 
 CORPUS = dict(util.corpus())
+CORPUS_LONG = dict(util.corpus_long())
 LEVELS = [l for l in GOLDEN["levels"] if util.oracle().lzo_level_supported(l)]
 
 
@@ -27,7 +28,7 @@ def test_levels_in_scope_are_restated():
 
 
 def test_datagen_matches_recorded_inputs():
-    for name, data in CORPUS.items():
+    for name, data in list(CORPUS.items()) + list(CORPUS_LONG.items()):
         assert util.sha(data) == GOLDEN["cases"][name]["input_sha256"], name
 
 
@@ -43,7 +44,7 @@ def test_datagen_matches_reference_generator():
 
 @pytest.mark.parametrize("level", LEVELS)
 def test_oracle_vs_golden(level):
-    for name, data in CORPUS.items():
+    for name, data in list(CORPUS.items()) + list(CORPUS_LONG.items()):
         out, r = util.compress_with(util.oracle().lzo_compress, data, level)
         g = GOLDEN["cases"][name]["out"][str(level)]
         assert r == g["size"], (name, level)

@@ -141,3 +141,26 @@ def corpus(small=False):
         ("text", (b"the quick brown fox jumps over the lazy dog. " * 6000)[:n]),
     ]
     return out
+
+
+def corpus_long():
+    """1 MiB+ inputs with repeats at distances around 2^16 and 2^17 (the reference's 65535-byte window
+    edge and the wrap points of position encodings that keep fewer bits than the position), sparse
+    long-distance markers in noise, and multi-MiB blocks (many sub-blocks, table persistence)."""
+    rnd = random.Random(99)
+    out = []
+    n = 1 << 20
+    for per in [65528, 65535, 65536, 65537, 65544, 131064, 131071, 131072, 131073, 131080, 196608, 262144, 98304, 32768, 40000]:
+        chunk = rnd.randbytes(per)
+        out.append((f"randperiod{per}", (chunk * (1 + n // per))[:n]))
+        chunk2 = datagen(per, 0.5, 0.0, per)
+        out.append((f"p50period{per}", (chunk2 * (1 + n // per))[:n]))
+    marker = rnd.randbytes(64)
+    for name, step in (("markers65529", 65536 - 7), ("markers131077", 131072 + 5)):
+        base = bytearray(rnd.randbytes(n))
+        for pos in range(1000, n - 100, step):
+            base[pos:pos + 64] = marker
+        out.append((name, bytes(base)))
+    out.append(("p50_4m", datagen(4 << 20, 0.5, 0.0, 5)))
+    out.append(("p20_2m", datagen(2 << 20, 0.2, 0.0, 6)))
+    return out
