@@ -174,6 +174,14 @@ def main():
     if rank == 0:
         avg_k = sum(kms) / len(kms) / 1e3
         alg_bytes = in_bytes + out_bytes                     # per launch on this GPU
+        traffic = None                                       # HBM bytes per launch from the committed PMC passes, if this config was profiled
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                for ent in json.load(f)["entries"]:
+                    if (ent["level"], ent["block_size"], ent["blocks_per_gpu"]) == (args.level, bs, nb):
+                        traffic = ent["traffic_bytes"]        # the LAST matching entry (latest round) wins
+        except (OSError, KeyError, ValueError):
+            pass
         res = {
             "metric": "compress MB/s (input), 256 KiB blocks level -10" if (args.level, bs) == (10, 262144)
                       else f"compress MB/s (input), {bs} B blocks level -{args.level}",
@@ -191,7 +199,7 @@ def main():
             "compressed_bytes": tot_out,
             "verified_blocks_bit_exact": verified,
             "roofline": {"bound": "hbm", "achieved": round(alg_bytes / avg_k / 1e9, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(alg_bytes / avg_k / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(alg_bytes / avg_k / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": {10: "lz_fast12_kernel<false>", 30: "lz_fast12_kernel<true>", 21: "lz_pricefast14_kernel<false>",
                                     41: "lz_pricefast14_kernel<true>"}.get(args.level, "?"), "avg_kernel_ms": round(avg_k * 1e3, 3),
                          "algorithmic_bytes_per_launch": alg_bytes},
