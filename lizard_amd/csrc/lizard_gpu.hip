@@ -32,6 +32,7 @@ template <bool HUF>
 __global__ __launch_bounds__(64) void lz_fast12_kernel(LzBatch a)
 {
     __shared__ u32 table[LZ_TAB_BYTES(LZ_EXP_HASHLOG) / 4u];
+    __shared__ u64 seqRing[LZ_SEQ_RING];
     __shared__ u32 tagws[HUF ? LZ_HUF_WS_WORDS : 1u];
     u8* tag = (u8*)tagws;
     u8* scratch = a.scratch + (u64)blockIdx.x * LZ_SCRATCH_BYTES;
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(64) void lz_fast12_kernel(LzBatch a)
         if (b >= a.nBlocks) break;
         const u32 n = (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
         const u32 c = lz_compress_block<LZ_PARSER_FAST, LZ_EXP_HASHLOG, 0, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
-                                                     a.level, table, tag, scratch);
+                                                     a.level, table, tag, scratch, seqRing);
         if (lz_lane() == 0) a.sizes[b] = c;
         lz_converge();
     }
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(64) void lz_pricefast14_kernel(LzBatch a)
         if (b >= a.nBlocks) break;
         const u32 n = (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
         const u32 c = lz_compress_block<LZ_PARSER_PRICEFAST, 14, 12, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
-                                                                        a.level, table, tag, scratch);
+                                                                        a.level, table, tag, scratch, nullptr);
         if (lz_lane() == 0) a.sizes[b] = c;
         lz_converge();
     }

@@ -43,12 +43,13 @@
 struct LzStreams {
     u8* lit;    u8* flags;  u8* off16;  u8* off24;      // scratch bases (each LZ_SUBBLOCK_PAD bytes)
     u32 nlit;   u32 nflags; u32 noff16; u32 noff24;     // uniform byte counts of the current sub-block
-    // fastLZ4 record whose literal loads are still in flight (stored by the NEXT lz_emit_lz4 / lz_emit_flush,
-    // so that no sequence waits for its own literal bytes): per lane bytes i and i+64 of the record
-    u32 pendLd0, pendLd1, pendCv0, pendCv1;             // loaded literal / computed byte, per lane
-    u32 pendLit;                                        // per lane: bit0/bit1 = byte i / i+64 is a literal
-    u32 pendN;                                          // uniform: record bytes pending (<= 128), 0 = none
-    u32 pendAt;                                         // uniform: offset of the record in the literals stream
+    // fast parser: the serial parse only appends (literal run, match length, offset) to a sequence list;
+    // the streams are produced afterwards by a wave-parallel pass (lz_encode_lz4)
+    u64* seq;   u32 nseq;                               // list base (scratch), uniform count
+    u64* ring;                                          // LDS: LZ_SEQ_RING most recent sequences, flushed to `seq` in
+                                                        // coalesced bursts — gfx950 counts stores in vmcnt, so a global
+                                                        // store per sequence would sit in front of every later load wait
+    u32 lastLits;                                       // uniform: trailing literals of the sub-block (fast.h:187-190)
     u32 sweepAt;                                        // uniform: position at which the 17-bit table is swept next
 #ifdef LZ_PROFILE
     u64 prof_last; u64 prof[8];                         // shader-clock deltas per phase (profile builds only)
@@ -62,13 +63,27 @@ struct LzStreams {
 #define LZ_PROF(st, k) ((void)0)
 #endif
 #define LZ_SCRATCH_BYTES (4u * LZ_SUBBLOCK_PAD)
+// Scratch slot of one wave (global memory).  priceFast: four stream staging areas of LZ_SUBBLOCK_PAD bytes.
+// Fast parser: [0, 256 KiB) sequence list (8 B per sequence, at most 131072/4 sequences per sub-block),
+// then a literals staging area and a flags staging area that only the Huffman levels use (levels without
+// Huffman write both streams straight into dst).
+#define LZ_SEQ_BYTES     (1u << 18)
+#define LZ_SEQ_RING      32u                            // sequences buffered in LDS (256 B per wave)
 
-LZ_DEV void lz_streams_bind(LzStreams& st, u8* scratch)
+LZ_DEV void lz_streams_bind(LzStreams& st, u8* scratch, bool fastParser, u64* ring)
 {
-    st.lit = scratch; st.flags = scratch + LZ_SUBBLOCK_PAD;
-    st.off16 = scratch + 2 * LZ_SUBBLOCK_PAD; st.off24 = scratch + 3 * LZ_SUBBLOCK_PAD;
+    st.ring = ring;
+    if (fastParser) {
+        st.seq = (u64*)scratch;
+        st.lit = scratch + LZ_SEQ_BYTES; st.flags = st.lit + LZ_SUBBLOCK_PAD;      // 256 KiB + 128 KiB+32 + 32 KiB < slot
+        st.off16 = st.off24 = st.flags;                                            // never written by fastLZ4 codewords
+    } else {
+        st.seq = (u64*)scratch;
+        st.lit = scratch; st.flags = scratch + LZ_SUBBLOCK_PAD;
+        st.off16 = scratch + 2 * LZ_SUBBLOCK_PAD; st.off24 = scratch + 3 * LZ_SUBBLOCK_PAD;
+    }
     st.nlit = st.nflags = st.noff16 = st.noff24 = 0;
-    st.pendN = 0; st.pendAt = 0; st.pendLd0 = st.pendLd1 = st.pendCv0 = st.pendCv1 = st.pendLit = 0;
+    st.nseq = 0; st.lastLits = 0;
 }
 
 // 64-bit-build hash of the reference: hash5 over an 8-byte little-endian read
@@ -143,63 +158,86 @@ LZ_DEV void lz_len_ext(bool present, u32 v, u32& word, u32& nbytes)
     else                   { word = 255u | (v << 8); nbytes = 4; }
 }
 
-// Store the record left pending by the previous lz_emit_lz4 (its literal loads have long completed).
-LZ_DEV void lz_emit_flush(LzStreams& st)
+// Bytes a fastLZ4 sequence adds to the literals stream (reference lib/lizard_compress_lz4.h:18-56):
+// literal-length escape + literals + LE16 offset + match-length escape.
+LZ_DEV u32 lz_ext_len(bool present, u32 v) { return !present ? 0u : v < 254u ? 1u : v < 65536u ? 3u : 4u; }
+LZ_DEV u32 lz_lz4_record_bytes(u32 L, u32 mlc)
 {
-    if (st.pendN) {
-        const u32 lane = lz_lane();
-        u8* out = st.lit + st.pendAt;
-        if (lane < st.pendN) out[lane] = (u8)((st.pendLit & 1u) ? st.pendLd0 : st.pendCv0);
-        if (lane + 64u < st.pendN) out[lane + 64u] = (u8)((st.pendLit & 2u) ? st.pendLd1 : st.pendCv1);
-        st.pendN = 0;
-    }
+    return lz_ext_len(L >= 15u, L - 15u) + L + 2u + lz_ext_len(mlc >= 15u, mlc - 15u);
 }
 
-// fastLZ4 sequence (reference lib/lizard_compress_lz4.h:3-71): token -> flags stream; literal-length
-// escape, literals, LE16 offset and match-length escape -> literals stream, as one contiguous record.
-// Each lane produces bytes i and i+64 of the record: the literal loads are only ISSUED here and the
-// first 128 bytes are stored by the next emit/flush; a longer record stores its remainder at once.
-LZ_DEV void lz_emit_lz4(const u8* src, u32 anchor, u32 P, u32 ml, u32 M, LzStreams& st)
+// Serial side of the encoder: one 8-byte LDS store per sequence, one coalesced global burst per
+// LZ_SEQ_RING sequences.  L < 2^18, ml-4 < 2^18, offset < 2^16.
+LZ_DEV void lz_seq_flush(LzStreams& st)
+{
+    const u32 pending = st.nseq & (LZ_SEQ_RING - 1u) ? st.nseq & (LZ_SEQ_RING - 1u) : (st.nseq ? LZ_SEQ_RING : 0u);
+    lz_lds_sync();
+    if (lz_lane() < pending) st.seq[st.nseq - pending + lz_lane()] = st.ring[lz_lane()];
+    lz_lds_sync();
+}
+LZ_DEV void lz_seq_push(LzStreams& st, u32 L, u32 ml, u32 off)
+{
+    const u32 mlc = ml - 4u;
+    if (lz_lane() == 0) st.ring[st.nseq & (LZ_SEQ_RING - 1u)] = (u64)L | ((u64)mlc << 18) | ((u64)off << 36);
+    lz_converge();
+    st.nseq += 1u; st.nflags += 1u;
+    st.nlit += lz_lz4_record_bytes(L, mlc);
+    if ((st.nseq & (LZ_SEQ_RING - 1u)) == 0) lz_seq_flush(st);
+}
+
+// Wave-parallel fastLZ4 encoder (reference lib/lizard_compress_lz4.h:3-86) over the sequence list of the
+// sub-block starting at src+S: 64 sequences per step, one per lane.  Tokens go to flagsOut (one coalesced
+// 64-byte store per step); record offsets inside litOut come from a wave prefix sum of the record sizes,
+// literal source positions from a prefix sum of literals+match lengths; every lane writes its own
+// escape/offset bytes, then the literal runs of the step are copied 8 sequences at a time (loads of 8
+// runs in flight before the first store).  Trailing literals are appended raw.
+LZ_DEV void lz_encode_lz4(const u8* src, u32 S, const LzStreams& st, u8* litOut, u8* flagsOut)
 {
     const u32 lane = lz_lane();
-    lz_emit_flush(st);
-    const u32 L = P - anchor, off = P - M, mlc = ml - 4u;
-    u32 extLw, extLn, extMw, extMn;
-    lz_len_ext(L >= 15u, L - 15u, extLw, extLn);
-    lz_len_ext(mlc >= 15u, mlc - 15u, extMw, extMn);
-    const u32 token = (L >= 15u ? 15u : L) | ((mlc >= 15u ? 15u : mlc) << 4);
-    const u32 oOff = extLn + L, oExtM = oOff + 2u, R = oExtM + extMn;
-    u32 lit = 0, ld0 = 0, ld1 = 0, cv0 = 0, cv1 = 0;
-    {
-        const u32 i = lane;
-        if (i < extLn)       cv0 = extLw >> (8u * i);
-        else if (i < oOff)   { lit |= 1u; ld0 = src[anchor + (i - extLn)]; }
-        else if (i < oExtM)  cv0 = off >> (8u * (i - oOff));
-        else                 cv0 = extMw >> (8u * (i - oExtM));
-    }
-    {
-        const u32 i = lane + 64u;
-        if (i < R) {
-            if (i < extLn)       cv1 = extLw >> (8u * i);
-            else if (i < oOff)   { lit |= 2u; ld1 = src[anchor + (i - extLn)]; }
-            else if (i < oExtM)  cv1 = off >> (8u * (i - oOff));
-            else                 cv1 = extMw >> (8u * (i - oExtM));
+    u32 srcPos = S, outPos = 0;                                   // uniform carries
+    for (u32 base = 0; base < st.nseq; base += 64u) {
+        const u32 cnt = st.nseq - base < 64u ? st.nseq - base : 64u;
+        u32 L = 0, mlc = 0, off = 0, R = 0, adv = 0;
+        if (lane < cnt) {
+            const u64 q = st.seq[base + lane];
+            L = (u32)q & 0x3FFFFu; mlc = (u32)(q >> 18) & 0x3FFFFu; off = (u32)(q >> 36);
+            R = lz_lz4_record_bytes(L, mlc); adv = L + mlc + 4u;
         }
+        const u32 myOut = outPos + lz_wave_scan_excl_add(R);
+        const u32 mySrc = srcPos + lz_wave_scan_excl_add(adv);
+        u32 extLw, extLn, extMw, extMn;
+        lz_len_ext(L >= 15u, L - 15u, extLw, extLn);
+        lz_len_ext(mlc >= 15u, mlc - 15u, extMw, extMn);
+        if (lane < cnt) {
+            flagsOut[base + lane] = (u8)((L >= 15u ? 15u : L) | ((mlc >= 15u ? 15u : mlc) << 4));
+            u8* r = litOut + myOut;
+            for (u32 k = 0; k < extLn; k++) r[k] = (u8)(extLw >> (8u * k));
+            r += extLn + L;
+            lz_st16(r, off);
+            for (u32 k = 0; k < extMn; k++) r[2u + k] = (u8)(extMw >> (8u * k));
+        }
+        // literal runs: lane k of the copy handles byte k (+64, +128, ...) of each run
+        const u32 litAt = myOut + extLn;
+        for (u32 j0 = 0; j0 < cnt; j0 += 8u) {
+            u32 v[8], o[8], n8[8];
+            for (u32 t = 0; t < 8u; t++) {                        // issue: first 64 bytes of 8 runs
+                const u32 j = j0 + t < cnt ? j0 + t : j0;         // (clamped duplicate is harmless: same bytes, same place)
+                const u32 a = lz_readlane(mySrc, j); o[t] = lz_readlane(litAt, j); n8[t] = lz_readlane(L, j);
+                v[t] = lane < n8[t] ? src[a + lane] : 0u;
+            }
+            for (u32 t = 0; t < 8u; t++)
+                if (lane < n8[t]) litOut[o[t] + lane] = (u8)v[t];
+            for (u32 t = 0; t < 8u; t++) {                        // rare: runs longer than 64 bytes
+                if (n8[t] > 64u && j0 + t < cnt) {
+                    const u32 a = lz_readlane(mySrc, j0 + t);
+                    for (u32 k = 64u + lane; k < n8[t]; k += 64u) litOut[o[t] + k] = src[a + k];
+                }
+            }
+        }
+        srcPos = lz_readlane(mySrc + adv, 63u);                   // lanes >= cnt hold adv == R == 0
+        outPos = lz_readlane(myOut + R, 63u);
     }
-    st.pendLd0 = ld0; st.pendLd1 = ld1; st.pendCv0 = cv0; st.pendCv1 = cv1; st.pendLit = lit;
-    st.pendN = R < 128u ? R : 128u; st.pendAt = st.nlit;
-    u8* out = st.lit + st.nlit;
-    for (u32 i = 128u + lane; i < R; i += 64u) {                 // rare: literal runs beyond ~120 bytes
-        u32 b;
-        if (i < extLn)       b = extLw >> (8u * i);
-        else if (i < oOff)   b = src[anchor + (i - extLn)];
-        else if (i < oExtM)  b = off >> (8u * (i - oOff));
-        else                 b = extMw >> (8u * (i - oExtM));
-        out[i] = (u8)b;
-    }
-    if (lane == 0) st.flags[st.nflags] = (u8)token;
-    lz_converge();
-    st.nlit += R; st.nflags += 1u;
+    lz_copy(litOut + outPos, src + srcPos, st.lastLits);          // lizard_compress_lz4.h:74-86
 }
 
 // Trailing literals of a sub-block (reference lib/lizard_compress_lz4.h:74-86): raw, no token.
@@ -222,8 +260,9 @@ LZ_DEV void lz_emit_last_literals(const u8* src, u32 anchor, u32 E, LzStreams& s
 //                its bytes are never fetched: most rounds issue no candidate gather at all.  Equal check
 //                bits prove nothing; those lanes still load and compare the real bytes.
 struct LzTab { u16* lo; u8* hi; };
-#define LZ_TAB_BYTES(HASHLOG) (3u << (HASHLOG))
-template <int HASHLOG> LZ_DEV LzTab lz_tab_bind(void* mem) { LzTab t; t.lo = (u16*)mem; t.hi = (u8*)mem + (2u << HASHLOG); return t; }
+// One extra slot (index 2^HASHLOG, "trash") lets lanes that must not store do so anyway, branch-free.
+#define LZ_TAB_BYTES(HASHLOG) ((3u << (HASHLOG)) + 4u)
+template <int HASHLOG> LZ_DEV LzTab lz_tab_bind(void* mem) { LzTab t; t.lo = (u16*)mem; t.hi = (u8*)mem + (2u << HASHLOG) + 2u; return t; }
 LZ_DEV u32 lz_tab_entry(u32 p, u32 first4) { return (p & 0x1FFFFu) | ((first4 * 2654435761u) >> 25 << 17); }
 LZ_DEV u32 lz_tab_get(const LzTab& t, u32 h) { return (u32)t.lo[h] | ((u32)t.hi[h] << 16); }
 LZ_DEV void lz_tab_set(const LzTab& t, u32 h, u32 ent) { t.lo[h] = (u16)ent; t.hi[h] = (u8)(ent >> 16); }
@@ -244,13 +283,12 @@ LZ_DEV void lz_tab_sweep(const LzTab& t, u32 Ps, bool fresh)
 // anchor == ip), slots >= 2 = visits 0.. of the search run starting at ip+1 (fast.h:184).
 LZ_DEV void lz_slot_pos(u32 ip, u32 special, u32 slot, u32 mflimit, u32& p, bool& valid, bool& putOnly)
 {
-    putOnly = false;
-    if (special && slot < 2u) { p = ip - 2u + 2u * slot; valid = true; putOnly = slot == 0; }   // ip <= mflimit guaranteed (fast.h:143)
-    else {
-        const u32 v = slot - 2u * special;
-        p = ip + special + lz_visit_off(v);
-        valid = p + lz_visit_step(v) <= mflimit;                         // fast.h:84, tested before the probe
-    }
+    const bool post = special && slot < 2u;                              // ip <= mflimit guaranteed (fast.h:143)
+    const u32 v = slot - 2u * special;                                   // (garbage when post; selected away)
+    const u32 pv = ip + special + lz_visit_off(v);
+    p = post ? ip - 2u + 2u * slot : pv;
+    valid = post || pv + lz_visit_step(v) <= mflimit;                    // fast.h:84, tested before the probe
+    putOnly = post && slot == 0;
 }
 
 // Memory-latency structure of a round (the parse is latency-bound: ~70 % of wave time is s_waitcnt):
@@ -267,7 +305,7 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const LzTab& table, LzStr
     const u64 laneBit = 1ull << lane;
     const u64 lanesBelow = laneBit - 1ull;
     u32 anchor = S;                                                  // uniform
-    if (E - S < LZ_MFLIMIT + 1u) { lz_emit_last_literals(src, anchor, E, st); return; }   // fast.h:63
+    if (E - S < LZ_MFLIMIT + 1u) { st.lastLits = E - S; st.nlit += E - S; return; }     // fast.h:63
     const u32 mflimit = E - LZ_MFLIMIT, matchlimit = E - LZ_LASTLITERALS;
     // fast.h:57-58 in block-relative positions: lowLimit is fixed at sub-block entry
     const u32 lowPos = S > LZ_MAX_DIST_LZ4 ? S - LZ_MAX_DIST_LZ4 : 0u;
@@ -278,37 +316,39 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const LzTab& table, LzStr
 
     u32 ip = S + 1u;        // uniform: run start, or (special==1) the post-match probe position
     u32 special = 0;        // uniform
-    u64 nextBytes = 0;      // source bytes of my slot in the coming round, loaded ahead
-    bool hasNext = false;   // uniform
+    // my slot of the coming round — position, flags and source bytes — is prepared one round ahead (for the
+    // slots the run reaches if the current round finds no match) or right after a match (first round of the
+    // next run): the visit-schedule arithmetic and the source load are off the round's critical path
+    u32 pNext; bool validNext, putOnlyNext;
+    u64 nextBytes;
+    lz_slot_pos(ip, 0u, lane, mflimit, pNext, validNext, putOnlyNext);
+    nextBytes = lz_ld64(src + (validNext ? pNext : S));
     for (;;) {
         // ---------------- search: rounds of 64 slots until a lane accepts ----------------
         u32 v0 = 0;         // uniform: slots consumed by earlier rounds of this run
         u32 P = 0, M = 0, ml = 0, back = 0;   // uniform: winner position, candidate, lengths
         for (;;) {
-            LZ_PROF(st, 3);                                              // (loop glue / encode tail)
-            u32 p; bool valid, putOnly;
-            lz_slot_pos(ip, special, v0 + lane, mflimit, p, valid, putOnly);
+            LZ_PROF(st, 3);                                              // loop glue, sequence push
+            const u32 p = pNext; const bool valid = validNext, putOnly = putOnlyNext;
+            const u64 bytes = nextBytes;
             u32 pAhead;                                                  // my slot's position in the next round of this run
             {
-                bool valid2, po2;
-                lz_slot_pos(ip, special, v0 + 64u + lane, mflimit, pAhead, valid2, po2);
-                if (!valid2) pAhead = S;                                 // any readable address
+                lz_slot_pos(ip, special, v0 + 64u + lane, mflimit, pAhead, validNext, putOnlyNext);
+                pNext = pAhead;
+                if (!validNext) pAhead = S;                              // any readable address
             }
             {   // keep every live slot younger than 2^17 positions (see LzTab)
                 const u32 p0 = lz_readlane(p, 0);
                 if (p0 >= st.sweepAt) { lz_tab_sweep<HASHLOG>(table, p0, false); st.sweepAt = p0 + 32768u; lz_lds_sync(); }
             }
-            u32 h = 0, e = 0, first4 = 0, mine = 0;
-            u64 bytes = 0;
-            if (valid) {
-                bytes = hasNext ? nextBytes : lz_ld64(src + p);
-                first4 = (u32)bytes;
-                h = lz_hash5<HASHLOG>(bytes);
-                mine = lz_tab_entry(p, first4);
-                e = lz_tab_get(table, h);                                // fast.h:86 (value before this round)
-            }
+            // (slots past mflimit hold stale bytes and a meaningless hash; `valid` keeps them out of every decision
+            //  and their stores go to the trash slot — the round itself is branch-free up to the candidate batch)
+            const u32 first4 = (u32)bytes;
+            const u32 h = lz_hash5<HASHLOG>(bytes);
+            const u32 mine = lz_tab_entry(p, first4);
+            u32 e = lz_tab_get(table, h);                                // fast.h:86 (value before this round)
             lz_converge();                                               // every lane has read before any lane puts
-            if (valid) lz_tab_set(table, h, mine);                       // speculative put (fast.h:88); undone below if needed
+            lz_tab_set(table, valid ? h : (1u << HASHLOG), mine);        // speculative put (fast.h:88); undone below if needed
             lz_lds_sync();
             // two slots of this round on one table slot: the later must see the earlier's put, in order
             // (positions of one round differ by < 2^16, so the low halves alone tell the writers apart)
@@ -335,26 +375,33 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const LzTab& table, LzStr
             const u32 ep = p - age;
             const bool cand = valid && !putOnly && ((e ^ mine) >> 17) == 0 && age >= LZ_MIN_OFFSET && age <= LZ_MAX_DIST_LZ4
                            && age <= p - lowPos;
-            u64 cA = 0, cB = 0, pB = 0, cZ = 0, pZ = 0;
+            u64 cA = 0, cB = 0, pB = 0, cC = 0, pC = 0, cZ = 0, pZ = 0;
             const bool haveBack = cand && ep >= 8u;                      // then p >= 16 as well
-            if (cand) {                                                  // one batch, straight-line: p + 16 <= E - 5
-                const u32 zb = haveBack ? 8u : 0u;
+            const bool have24 = p + 24u <= E;                            // third 8 bytes readable inside the sub-block
+            if (cand) {                                                  // one batch, straight-line (p + 16 <= E - 5)
+                const u32 zb = haveBack ? 8u : 0u, fc = have24 ? 16u : 0u;
                 cA = lz_ld64(src + ep); cB = lz_ld64(src + ep + 8u); pB = lz_ld64(src + p + 8u);
+                cC = lz_ld64(src + ep + fc); pC = lz_ld64(src + p + fc);
                 cZ = lz_ld64(src + ep - zb); pZ = lz_ld64(src + p - zb);
             }
             // source bytes for the next round of this run (consumed only if no lane accepts).  Always
             // issued and assigned unconditionally: no select forces the load to complete inside this
             // round and the vmcnt arithmetic of the batch above stays exact.
             nextBytes = lz_ld64(src + pAhead);
-            hasNext = true;
             LZ_PROF(st, 0);                                              // round part A: bytes wait, hash, LDS, filter, loads issued
             const bool ok = cand && (u32)cA == first4;                   // fast.h:97
-            // lengths from the batch: common prefix < 16 and common suffix < 8 are exact, 0xFF = unresolved
-            u32 fwd = 0xFFu, bwd = 0xFFu;
+            // match lengths from the batch, already clamped like the reference's counts (fast.h:100,102):
+            // exact when the difference (or the limit) lies inside the fetched bytes, else 0xFFFF = unresolved
+            u32 fwd = 0xFFFFu, bwd = 0xFFFFu;
             {
-                const u64 x = bytes ^ cA, y = pB ^ cB, z = pZ ^ cZ;
-                if (x) fwd = lz_ctz64(x) >> 3; else if (y) fwd = 8u + (lz_ctz64(y) >> 3);
-                if (haveBack && z) bwd = lz_clz64(z) >> 3;
+                const u64 x = bytes ^ cA, y = pB ^ cB, y2 = pC ^ cC, z = pZ ^ cZ;
+                const u32 seen = have24 ? 24u : 16u;
+                const u32 common = x ? lz_ctz64(x) >> 3 : y ? 8u + (lz_ctz64(y) >> 3) : (have24 && y2) ? 16u + (lz_ctz64(y2) >> 3) : seen;
+                const u32 room = matchlimit - p;                         // p < matchlimit for every valid slot
+                if (common < seen || room <= seen) fwd = common < room ? common : room;
+                const u32 roomB = (p - anchor) < ep ? (p - anchor) : ep;
+                const u32 cb = !haveBack ? 0u : z ? lz_clz64(z) >> 3 : 8u;
+                if (roomB <= cb || (haveBack && cb < 8u)) bwd = cb < roomB ? cb : roomB;
             }
             lz_pin(fwd); lz_pin(bwd);                                    // computed here, under this batch's counted wait
             const u64 okMask = lz_ballot(ok);                            // uniform
@@ -363,13 +410,13 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const LzTab& table, LzStr
             u64 commit = validMask;
             if (okMask) { w = lz_ctz64(okMask); commit = validMask & (~0ull >> (63u - w)); }
             // settle the table slots: slots after the winner never happened (the reference stopped there)
-            if (valid) {
-                if (grp == laneBit) { if (!(commit & laneBit)) lz_tab_set(table, h, eOld); }          // undo my put
-                else {
-                    const u64 c = grp & commit;
-                    if (c) { if (lane == 63u - lz_clz64(c)) lz_tab_set(table, h, mine); }             // last committed slot wins
-                    else if (lane == lz_ctz64(grp)) lz_tab_set(table, h, eOld);                       // whole group undone
-                }
+            {
+                const u64 c = grp & commit;                              // committed slots on my table slot
+                const bool single = grp == laneBit;
+                const bool undo = single ? !(commit & laneBit)           // my own put did not happen
+                                         : (c == 0 && (grp & lanesBelow) == 0);   // whole group undone: its first lane restores
+                const bool redo = !single && c != 0 && (c >> lane) == 1ull;       // last committed slot of the group wins
+                lz_tab_set(table, (valid && (undo || redo)) ? h : (1u << HASHLOG), undo ? eOld : mine);
             }
             lz_lds_sync();
             LZ_PROF(st, 1);                                              // round part B: candidate wait, ballots, slot settle
@@ -382,35 +429,23 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const LzTab& table, LzStr
             v0 += 64u;
         }
         // ---------------- extend ----------------
-        if (ml != 0xFFu) { const u32 room = matchlimit - P; ml = ml < room ? ml : room; }        // fast.h:100: count stops at matchlimit
-        else ml = 4u + lz_count_fwd(src, P + 4u, M + 4u, matchlimit);
-        {
-            const u32 roomP = P - anchor, roomB = roomP < M ? roomP : M;                         // fast.h:102 bounds
-            if (back != 0xFFu) back = back < roomB ? back : roomB;
-            else back = lz_count_back(src, P, M, anchor);
-        }
+        if (ml == 0xFFFFu) ml = 4u + lz_count_fwd(src, P + 4u, M + 4u, matchlimit);            // fast.h:100
+        if (back == 0xFFFFu) back = lz_count_back(src, P, M, anchor);                           // fast.h:102
         P -= back; M -= back; ml += back;
         ip = P + ml;
         LZ_PROF(st, 2);                                                  // extension
-        if (ip > mflimit) {                                              // fast.h:143
-            lz_emit_lz4(src, anchor, P, ml, M, st); anchor = ip;
-            goto tail;
-        }
-        // first round of the next run: fetch its source bytes now, so that encoding overlaps the loads
-        special = 1u; hasNext = true;
-        {
-            u32 p2; bool valid2, po2;
-            lz_slot_pos(ip, 1u, lane, mflimit, p2, valid2, po2);
-            nextBytes = valid2 ? lz_ld64(src + p2) : 0ull;
-        }
-        lz_emit_lz4(src, anchor, P, ml, M, st);                          // fast.h:138
+        lz_seq_push(st, P - anchor, ml, P - M);                          // fast.h:138 (encoded later, in parallel)
         anchor = ip;
+        if (ip > mflimit) goto tail;                                     // fast.h:143
+        // first round of the next run
+        special = 1u;
+        lz_slot_pos(ip, 1u, lane, mflimit, pNext, validNext, putOnlyNext);
+        nextBytes = lz_ld64(src + (validNext ? pNext : S));
     }
 tail:
+    if (st.nseq & (LZ_SEQ_RING - 1u)) lz_seq_flush(st);
+    st.lastLits = E - anchor; st.nlit += E - anchor;                     // fast.h:187-190
     LZ_PROF(st, 3);
-    lz_emit_flush(st);
-    lz_emit_last_literals(src, anchor, E, st);                           // fast.h:187-190
-    LZ_PROF(st, 4);                                                      // trailing literals
 }
 
 LZ_DEV void lz_st24(u8* p, u32 v) { p[0] = (u8)v; p[1] = (u8)(v >> 8); p[2] = (u8)(v >> 16); }
@@ -488,19 +523,67 @@ LZ_DEV u32 lz_write_subblock_huf(const u8* in, u32 n, u8* op, LzStreams& st, u32
     return total;
 }
 
+// Lizard_writeBlock for the fast parser (reference lib/lizard_compress.c:186-250): the stream sizes are
+// known from the parse (nseq tokens, nlit literal-stream bytes), so the raw-fallback rules of :201 are
+// decided before a single output byte exists; without Huffman also :228, and both streams are encoded
+// straight into their final place in dst.  With Huffman they are encoded into the staging areas first
+// (the entropy stage needs them contiguous), then written like lz_write_subblock_huf.
+template <bool HUF>
+LZ_DEV u32 lz_write_subblock_fast(const u8* src, u32 S, u32 E, u8* op, LzStreams& st, u32* ws)
+{
+    const u32 n = E - S, sum = st.nflags + st.nlit;
+    bool raw = st.nlit < LZ_LASTLITERALS || sum + 16u > n;             // lizard_compress.c:201
+    u32 total = 16u + sum;
+    if (!HUF) raw = raw || total + total / 32u + 512u > n;             // :228 (sizes are final without Huffman)
+    if (!raw) {
+        lz_wave_sync();                                                // sequence list written by lane 0
+        if constexpr (!HUF) {
+            if (lz_lane() == 0) {
+                op[0] = 0; lz_st24(op + 1, 0); lz_st24(op + 4, 0); lz_st24(op + 7, 0);   // header, empty len/off16/off24 (:203-213)
+                lz_st24(op + 10, st.nflags); lz_st24(op + 13 + st.nflags, st.nlit);      // :215, :221
+            }
+            lz_converge();
+            lz_encode_lz4(src, S, st, op + 16u + st.nflags, op + 13u);
+        } else {
+            lz_encode_lz4(src, S, st, st.lit, st.flags);
+            lz_wave_sync();
+            u32 hf = 0, hl = 0;
+            u8* q = op + 1;
+            if (lz_lane() == 0) { lz_st24(q, 0); lz_st24(q + 3, 0); lz_st24(q + 6, 0); }
+            lz_converge();
+            q += 9;
+            q += lz_put_stream_huf(q, st.flags, st.nflags, ws, &hf);   // LIZARD_FLAG_FLAGS = 2
+            q += lz_put_stream_huf(q, st.lit, st.nlit, ws, &hl);       // LIZARD_FLAG_LITERALS = 1
+            total = (u32)(q - op);
+            if (lz_lane() == 0) op[0] = (u8)(hl * 1u + hf * 2u);
+            lz_converge();
+            raw = total + total / 32u + 512u > n;                      // :228
+        }
+    }
+    if (raw) {
+        lz_wave_sync();
+        if (lz_lane() == 0) { op[0] = 128; lz_st24(op + 1, n); }       // LIZARD_FLAG_UNCOMPRESSED, :239-244
+        lz_converge();
+        lz_copy(op + 4, src + S, n);
+        return n + 4u;
+    }
+    return total;
+}
+
 // ---- one API block: reference Lizard_compress_extState on a zeroed state (lizard_compress.c:583) ----
 // dst must have room for Lizard_compressBound(n) bytes. Returns the compressed size (uniform).
+// seqRing:  fast parser -> LZ_SEQ_RING u64 of LDS (may be null for priceFast).
 // tableMem: fast parser -> LZ_TAB_BYTES(HASHLOG) bytes (24-bit slots, see LzTab); priceFast -> 4 << HASHLOG bytes.
 // AUX:      priceFast only -> TAGLOG of the round tag array.
 // PARSER: 0 = fastSmall/fast + fastLZ4 codewords, 1 = priceFast + LIZv1 codewords.
 #define LZ_PARSER_FAST      0
 #define LZ_PARSER_PRICEFAST 1
 template <int PARSER, int HASHLOG, int AUX, bool HUF>
-LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tableMem, u8* ws, u8* scratch)
+LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tableMem, u8* ws, u8* scratch, u64* seqRing)
 {
     const u32 lane = lz_lane();
     LzStreams st;
-    lz_streams_bind(st, scratch);
+    lz_streams_bind(st, scratch, PARSER == LZ_PARSER_FAST, seqRing);
 #ifdef LZ_PROFILE
     st.prof_last = __builtin_readcyclecounter();
     for (int k = 0; k < 8; k++) st.prof[k] = 0;
@@ -517,10 +600,12 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
     for (u32 pos = 0; pos < n; ) {                            // lizard_compress.c:494
         const u32 part = (n - pos) < LZ_SUBBLOCK ? (n - pos) : LZ_SUBBLOCK;
         st.nlit = st.nflags = st.noff16 = st.noff24 = 0;      // Lizard_initBlock, :130-138
+        st.nseq = 0; st.lastLits = 0;
         if constexpr (PARSER == LZ_PARSER_FAST) lz_parse_fast<HASHLOG>(src, pos, pos + part, tab, st);
         else                                    lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, table, ws, st);
-        if constexpr (HUF) op += lz_write_subblock_huf(src + pos, part, dst + op, st, (u32*)ws);
-        else               op += lz_write_subblock_raw_streams(src + pos, part, dst + op, st);
+        if constexpr (PARSER == LZ_PARSER_FAST) op += lz_write_subblock_fast<HUF>(src, pos, pos + part, dst + op, st, (u32*)ws);
+        else if constexpr (HUF)                 op += lz_write_subblock_huf(src + pos, part, dst + op, st, (u32*)ws);
+        else                                    op += lz_write_subblock_raw_streams(src + pos, part, dst + op, st);
         lz_wave_sync();                                       // scratch is reused by the next sub-block
         LZ_PROF(st, 5);                                       // container: stream copies / Huffman
         pos += part;

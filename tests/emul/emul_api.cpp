@@ -4,13 +4,13 @@
 #include "../../lizard_amd/csrc/lz_block.h"
 
 namespace {
-struct Args { const u8* src; u32 n; u8* dst; u32 level; u32* table; u8* tag; u8* scratch; u32 result; };
+struct Args { const u8* src; u32 n; u8* dst; u32 level; u32* table; u8* tag; u8* scratch; u64* ring; u32 result; };
 
 template <int PARSER, int HASHLOG, int AUX, bool HUF>
 void entry_block(void* a)
 {
     Args* x = (Args*)a;
-    u32 r = lz_compress_block<PARSER, HASHLOG, AUX, HUF>(x->src, x->n, x->dst, x->level, x->table, x->tag, x->scratch);
+    u32 r = lz_compress_block<PARSER, HASHLOG, AUX, HUF>(x->src, x->n, x->dst, x->level, x->table, x->tag, x->scratch, x->ring);
     if (lz_lane() == 0) x->result = r;
 }
 }  // namespace
@@ -29,6 +29,7 @@ extern "C" int emul_compress_block(const void* src, int n, void* dst, int level,
     a.table = (u32*)malloc(sizeof(u32) << hashLog);
     a.tag = (u8*)malloc(8192);
     a.scratch = (u8*)malloc(LZ_SCRATCH_BYTES);
+    u64 ring[LZ_SEQ_RING]; memset(ring, 0xEE, sizeof ring); a.ring = ring;
     memset(a.table, 0xA5, sizeof(u32) << hashLog);   // garbage: the kernel must initialise its state
     memset(a.tag, 0x5A, 8192);
     memset(a.scratch, 0xCC, LZ_SCRATCH_BYTES);

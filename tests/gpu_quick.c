@@ -99,6 +99,7 @@ int main(int argc, char** argv)
             for (int r = 0; r < reps && !rc; r++) {
                 rc = LizardGPU_compressBlocks_host(buf, nb, bs, bs, out, stride, cs, level);
                 ms = LizardGPU_lastKernelMs();
+                if (reps > 2) printf("    rep %d: kernel %.3f ms\n", r, ms);
             }
             g_deadline = 0;
             size_t tot = 0; int bad = rc != 0;
