@@ -216,21 +216,40 @@ LZ_DEV void lz_encode_lz4(const u8* src, u32 S, const LzStreams& st, u8* litOut,
             lz_st16(r, off);
             for (u32 k = 0; k < extMn; k++) r[2u + k] = (u8)(extMw >> (8u * k));
         }
-        // literal runs: lane k of the copy handles byte k (+64, +128, ...) of each run
+        // literal runs.  Vector-memory cost on this path is per instruction, not per byte, so one
+        // load/store pair serves EIGHT runs: lane l works on run 8g + (l >> 3) with sub-lane s = l & 7.
+        // Runs of >= 8 bytes move 8 bytes per sub-lane (the last piece is pulled back to end exactly at
+        // the run's end; overlapping pieces rewrite identical bytes), shorter runs one byte per sub-lane.
+        // All loads of the step are issued before the first store (loads and stores return through one
+        // in-order counter on gfx950).
         const u32 litAt = myOut + extLn;
-        for (u32 j0 = 0; j0 < cnt; j0 += 8u) {
-            u32 v[8], o[8], n8[8];
-            for (u32 t = 0; t < 8u; t++) {                        // issue: first 64 bytes of 8 runs
-                const u32 j = j0 + t < cnt ? j0 + t : j0;         // (clamped duplicate is harmless: same bytes, same place)
-                const u32 a = lz_readlane(mySrc, j); o[t] = lz_readlane(litAt, j); n8[t] = lz_readlane(L, j);
-                v[t] = lane < n8[t] ? src[a + lane] : 0u;
+        {
+            u64 w8[8]; u32 w1[8];
+            #pragma unroll
+            for (u32 g = 0; g < 8u; g++) {
+                const u32 jr = 8u * g + (lane >> 3), sl = lane & 7u;
+                const u32 a = lz_shfl(mySrc, jr), nj = lz_shfl(L, jr);
+                const u32 n64 = nj < 64u ? nj : 64u;              // bytes beyond 64 are copied below
+                const u32 k = 8u * sl + 8u <= n64 ? 8u * sl : n64 - 8u;
+                w8[g] = (n64 >= 8u && 8u * sl < n64) ? lz_ld64(src + a + k) : 0ull;
+                w1[g] = (n64 < 8u && sl < n64) ? src[a + sl] : 0u;
             }
-            for (u32 t = 0; t < 8u; t++)
-                if (lane < n8[t]) litOut[o[t] + lane] = (u8)v[t];
-            for (u32 t = 0; t < 8u; t++) {                        // rare: runs longer than 64 bytes
-                if (n8[t] > 64u && j0 + t < cnt) {
-                    const u32 a = lz_readlane(mySrc, j0 + t);
-                    for (u32 k = 64u + lane; k < n8[t]; k += 64u) litOut[o[t] + k] = src[a + k];
+            #pragma unroll
+            for (u32 g = 0; g < 8u; g++) {
+                const u32 jr = 8u * g + (lane >> 3), sl = lane & 7u;
+                const u32 o = lz_shfl(litAt, jr), nj = lz_shfl(L, jr);
+                const u32 n64 = nj < 64u ? nj : 64u;
+                const u32 k = 8u * sl + 8u <= n64 ? 8u * sl : n64 - 8u;
+                if (n64 >= 8u && 8u * sl < n64) lz_st64(litOut + o + k, w8[g]);
+                if (n64 < 8u && sl < n64) litOut[o + sl] = (u8)w1[g];
+            }
+        }
+        if (lz_ballot(L > 64u)) {                                 // rare: runs longer than 64 bytes
+            for (u32 j = 0; j < cnt; j++) {
+                const u32 nj = lz_readlane(L, j);
+                if (nj > 64u) {
+                    const u32 a = lz_readlane(mySrc, j), o = lz_readlane(litAt, j);
+                    for (u32 k = 64u + lane; k < nj; k += 64u) litOut[o + k] = src[a + k];
                 }
             }
         }
@@ -606,8 +625,9 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
         if constexpr (PARSER == LZ_PARSER_FAST) op += lz_write_subblock_fast<HUF>(src, pos, pos + part, dst + op, st, (u32*)ws);
         else if constexpr (HUF)                 op += lz_write_subblock_huf(src + pos, part, dst + op, st, (u32*)ws);
         else                                    op += lz_write_subblock_raw_streams(src + pos, part, dst + op, st);
+        LZ_PROF(st, 5);                                       // container: encode pass / stream copies / Huffman
         lz_wave_sync();                                       // scratch is reused by the next sub-block
-        LZ_PROF(st, 5);                                       // container: stream copies / Huffman
+        LZ_PROF(st, 4);                                       // draining the sub-block's stores
         pos += part;
     }
 #ifdef LZ_PROFILE

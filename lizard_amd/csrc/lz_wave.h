@@ -113,4 +113,5 @@ LZ_DEV u32 lz_ld32(const u8* p) { return reinterpret_cast<const lz_u32u*>(p)->v;
 LZ_DEV u64 lz_ld64(const u8* p) { return reinterpret_cast<const lz_u64u*>(p)->v; }
 LZ_DEV void lz_st16(u8* p, u32 v) { reinterpret_cast<lz_u16u*>(p)->v = (u16)v; }
 LZ_DEV void lz_st32(u8* p, u32 v) { reinterpret_cast<lz_u32u*>(p)->v = v; }
+LZ_DEV void lz_st64(u8* p, u64 v) { reinterpret_cast<lz_u64u*>(p)->v = v; }
 #endif  /* LZ_WAVE_H_ */

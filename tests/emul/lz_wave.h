@@ -134,4 +134,5 @@ LZ_DEV u32 lz_ld32(const u8* p) { u32 v; memcpy(&v, p, 4); return v; }
 LZ_DEV u64 lz_ld64(const u8* p) { u64 v; memcpy(&v, p, 8); return v; }
 LZ_DEV void lz_st16(u8* p, u32 v) { u16 x = (u16)v; memcpy(p, &x, 2); }
 LZ_DEV void lz_st32(u8* p, u32 v) { memcpy(p, &v, 4); }
+LZ_DEV void lz_st64(u8* p, u64 v) { memcpy(p, &v, 8); }
 #endif  /* LZ_WAVE_H_ */

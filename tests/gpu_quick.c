@@ -119,7 +119,7 @@ int main(int argc, char** argv)
                 int (*dump)(unsigned long long*) = (int (*)(unsigned long long*))dlsym(RTLD_DEFAULT, "LizardGPU_profileDump");
                 unsigned long long pr[8];
                 if (dump && dump(pr) == 0) {
-                    static const char* nm[8] = { "roundA(bytes,hash,LDS,filter)", "roundB(cand wait,settle)", "extension", "glue+encode", "tail literals", "container", "table init", "-" };
+                    static const char* nm[8] = { "roundA(bytes,hash,LDS,filter)", "roundB(cand wait,settle)", "extension", "glue+encode", "store drain", "container", "table init", "-" };
                     double sum = 0; for (int k = 0; k < 8; k++) sum += (double)pr[k];
                     for (int k = 0; k < 7; k++) printf("    prof %-32s %6.2f %%  %.3g clk\n", nm[k], 100.0 * pr[k] / sum, (double)pr[k]);
                 }
