@@ -325,18 +325,18 @@ int LizardGPU_datagen_device(void* d_dst, size_t nBlocks, size_t blockSize, doub
 
 #ifdef LZ_PROFILE
 // Profile builds only: sum of the per-wave phase clocks since the last call (scratch slot heads), then reset.
-int LizardGPU_profileDump(unsigned long long out[8])
+int LizardGPU_profileDump(unsigned long long out[16])
 {
     pthread_mutex_lock(&g_mu);
     int rc = ctx_init_locked();
-    for (int k = 0; k < 8; k++) out[k] = 0;
+    for (int k = 0; k < 16; k++) out[k] = 0;
     if (!rc) {
         (void)hipDeviceSynchronize();
         for (int w = 0; w < g_ctx.waves; w++) {
-            unsigned long long v[8];
-            if (hipMemcpy(v, g_ctx.scratch + (size_t)(w + 1) * LZ_SCRATCH_BYTES - 64, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) { rc = -LIZARDGPU_ERR_HIP; break; }
-            for (int k = 0; k < 8; k++) out[k] += v[k];
-            (void)hipMemset(g_ctx.scratch + (size_t)(w + 1) * LZ_SCRATCH_BYTES - 64, 0, sizeof v);
+            unsigned long long v[16];
+            if (hipMemcpy(v, g_ctx.scratch + (size_t)(w + 1) * LZ_SCRATCH_BYTES - 128, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) { rc = -LIZARDGPU_ERR_HIP; break; }
+            for (int k = 0; k < 15; k++) out[k] += v[k];
+            (void)hipMemset(g_ctx.scratch + (size_t)(w + 1) * LZ_SCRATCH_BYTES - 128, 0, sizeof v);
         }
     }
     pthread_mutex_unlock(&g_mu);

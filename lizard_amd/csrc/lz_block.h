@@ -52,13 +52,13 @@ struct LzStreams {
     u32 lastLits;                                       // uniform: trailing literals of the sub-block (fast.h:187-190)
     u32 sweepAt;                                        // uniform: position at which the 17-bit table is swept next
 #ifdef LZ_PROFILE
-    u64 prof_last; u64 prof[8];                         // shader-clock deltas per phase (profile builds only)
+    u64 prof_last; u64 prof[16];                         // shader-clock deltas per phase (profile builds only)
 #endif
 };
 // Phase profiling exists only in -DLZ_PROFILE builds of the library (lizard_amd/variants/prof), never in
 // the shipped liblizard_amd.so: LZ_PROF(st, k) adds the shader clocks since the previous mark to slot k.
 #ifdef LZ_PROFILE
-#define LZ_PROF(st, k) do { const u64 t_ = __builtin_readcyclecounter(); (st).prof[k] += t_ - (st).prof_last; (st).prof_last = t_; } while (0)
+#define LZ_PROF(st, k) do { const u64 t_ = __builtin_readcyclecounter(); (st).prof[k] += t_ - (st).prof_last; (st).prof_last = t_; (st).prof[15] = t_; } while (0)
 #else
 #define LZ_PROF(st, k) ((void)0)
 #endif
@@ -525,8 +525,8 @@ LZ_DEV u32 lz_write_subblock_huf(const u8* in, u32 n, u8* op, LzStreams& st, u32
         q += 3;
         q += lz_put_stream_raw(q, st.off16, st.noff16);
         q += lz_put_stream_raw(q, st.off24, st.noff24);
-        q += lz_put_stream_huf(q, st.flags, st.nflags, ws, &hf);       // LIZARD_FLAG_FLAGS = 2
-        q += lz_put_stream_huf(q, st.lit, st.nlit, ws, &hl);           // LIZARD_FLAG_LITERALS = 1
+        q += lz_put_stream_huf(q, st.flags, st.nflags, ws, &hf LZ_HPROF_ARG(st));       // LIZARD_FLAG_FLAGS = 2
+        q += lz_put_stream_huf(q, st.lit, st.nlit, ws, &hl LZ_HPROF_ARG(st));           // LIZARD_FLAG_LITERALS = 1
         total = (u32)(q - op);
         if (lz_lane() == 0) op[0] = (u8)(hl * 1u + hf * 2u);
         lz_converge();
@@ -571,8 +571,8 @@ LZ_DEV u32 lz_write_subblock_fast(const u8* src, u32 S, u32 E, u8* op, LzStreams
             if (lz_lane() == 0) { lz_st24(q, 0); lz_st24(q + 3, 0); lz_st24(q + 6, 0); }
             lz_converge();
             q += 9;
-            q += lz_put_stream_huf(q, st.flags, st.nflags, ws, &hf);   // LIZARD_FLAG_FLAGS = 2
-            q += lz_put_stream_huf(q, st.lit, st.nlit, ws, &hl);       // LIZARD_FLAG_LITERALS = 1
+            q += lz_put_stream_huf(q, st.flags, st.nflags, ws, &hf LZ_HPROF_ARG(st));   // LIZARD_FLAG_FLAGS = 2
+            q += lz_put_stream_huf(q, st.lit, st.nlit, ws, &hl LZ_HPROF_ARG(st));       // LIZARD_FLAG_LITERALS = 1
             total = (u32)(q - op);
             if (lz_lane() == 0) op[0] = (u8)(hl * 1u + hf * 2u);
             lz_converge();
@@ -605,7 +605,7 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
     lz_streams_bind(st, scratch, PARSER == LZ_PARSER_FAST, seqRing);
 #ifdef LZ_PROFILE
     st.prof_last = __builtin_readcyclecounter();
-    for (int k = 0; k < 8; k++) st.prof[k] = 0;
+    for (int k = 0; k < 16; k++) st.prof[k] = 0;
 #endif
     LzTab tab = lz_tab_bind<HASHLOG>(tableMem);
     u32* table = (u32*)tableMem;
@@ -631,7 +631,7 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
         pos += part;
     }
 #ifdef LZ_PROFILE
-    if (lane == 0) { u64* pr = (u64*)(scratch + LZ_SCRATCH_BYTES - 64u); for (int k = 0; k < 8; k++) pr[k] += st.prof[k]; }   // per-wave totals at the tail of its scratch slot
+    if (lane == 0) { u64* pr = (u64*)(scratch + LZ_SCRATCH_BYTES - 128u); for (int k = 0; k < 15; k++) pr[k] += st.prof[k]; }   // per-wave totals at the tail of its scratch slot
     lz_converge();
 #endif
     return op;

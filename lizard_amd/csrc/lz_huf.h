@@ -13,8 +13,21 @@
 //                  and accepted ones are written straight to their final place in dst
 //   bit packing    4 symbols per lane per step, wave prefix sum of bit lengths, ds_or into an LDS
 //                  staging ring, whole dwords stored coalesced              (huf_compress.c:427-513)
+// All cross-lane hand-offs in this file go through LDS (histogram, tables, staging ring, the header size),
+// so lz_lds_sync() is the ordering point: it does not wait for the wave's pending global stores.
 #pragma once
 #include "lz_wave.h"
+
+// Sub-phase clocks of the stage in -DLZ_PROFILE builds (slots 8..14 of the per-wave profile record).
+#ifdef LZ_PROFILE
+#define LZ_HPROF_PARAM , u64* hp_
+#define LZ_HPROF_ARG(st) , (st).prof
+#define LZ_HPROF(k) do { const u64 t_ = __builtin_readcyclecounter(); hp_[k] += t_ - hp_[15]; hp_[15] = t_; } while (0)
+#else
+#define LZ_HPROF_PARAM
+#define LZ_HPROF_ARG(st)
+#define LZ_HPROF(k) ((void)0)
+#endif
 
 #define LZ_HUF_MAXBITS     12u    // HUF_TABLELOG_MAX, huf.h:118
 #define LZ_HUF_DEFAULTLOG  11u    // HUF_TABLELOG_DEFAULT, huf.h:119
@@ -289,7 +302,7 @@ LZ_DEV void lz_huf_pack_segment(const u8* src, u32 a, u32 b, u8* out, u32 nbytes
 {
     const u32 lane = lz_lane();
     for (u32 i = lane; i < LZ_HUF_STAGE_WORDS; i += 64u) stage[i] = 0;
-    lz_wave_sync();
+    lz_lds_sync();
     u32 cur = 0;            // uniform: bits pending in stage[0] (< 32)
     u32 wordsOut = 0;       // uniform: dwords already stored to `out`
     u32 remaining = b - a;  // uniform: symbols not yet appended; next to append is src[a + remaining - 1]
@@ -319,28 +332,28 @@ LZ_DEV void lz_huf_pack_segment(const u8* src, u32 a, u32 b, u8* out, u32 nbytes
             if (w1) lz_lds_atomic_or(&stage[w + 1u], w1);
             if (w2) lz_lds_atomic_or(&stage[w + 2u], w2);
         }
-        lz_wave_sync();
+        lz_lds_sync();
         const u32 T = cur + total, full = T >> 5;
         // store the completed dwords (<= 97 per step), coalesced
         for (u32 i = lane; i < full; i += 64u) lz_st32(out + 4u * (wordsOut + i), stage[i]);
         const u32 carry = stage[full];
-        lz_wave_sync();
+        lz_lds_sync();
         for (u32 i = lane; i < LZ_HUF_STAGE_WORDS; i += 64u) stage[i] = (i == 0) ? carry : 0u;
-        lz_wave_sync();
+        lz_lds_sync();
         wordsOut += full; cur = T & 31u; remaining -= take;
     }
     // end mark + the last partial dword, byte by byte
     const u32 lastWord = stage[0] | (1u << cur);
     const u32 done = 4u * wordsOut;
     if (lane < 4u && done + lane < nbytes) out[done + lane] = (u8)(lastWord >> (8u * lane));
-    lz_wave_sync();
+    lz_lds_sync();
 }
 
 // Lizard_writeStream for a Huffman candidate (lizard_compress.c:141-183) at `op`:
 //   accepted  -> LE24 n, LE24 c, c bytes of huff0 payload;  returns 6 + c and sets *huffed = 1
 //   otherwise -> LE24 n, raw bytes;                          returns 3 + n and sets *huffed = 0
 // ws = LZ_HUF_WS_WORDS words of LDS (may alias the parser's tag array). All lanes call.
-LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huffed)
+LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huffed LZ_HPROF_PARAM)
 {
     const u32 lane = lz_lane();
     *huffed = 0;
@@ -360,9 +373,10 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
     u32* fse = ws + LZ_HUF_WS_FSE;
     u8* payload = op + 6;
 
+    LZ_HPROF(14);
     // ---- histogram (FSE_count_wksp, fse_compress.c:431) ----
     for (u32 i = lane; i < 256u; i += 64u) count[i] = 0;
-    lz_wave_sync();
+    lz_lds_sync();
     {
         const u32 n4 = n & ~3u;
         for (u32 i = lane * 4u; i < n4; i += 256u) {
@@ -374,11 +388,12 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
         }
         for (u32 i = n4 + lane; i < n; i += 64u) lz_lds_atomic_add(&count[stream[i]], 1u);
     }
-    lz_wave_sync();
+    lz_lds_sync();
     u32 c4[4];
     for (u32 k = 0; k < 4u; k++) c4[k] = count[lane * 4u + k];
     u32 myMax = c4[0], myTop = 0; bool any = c4[0] != 0;
     for (u32 k = 1; k < 4u; k++) { if (c4[k] > myMax) myMax = c4[k]; if (c4[k]) { myTop = k; any = true; } }
+    LZ_HPROF(8);                                               // histogram
     const u32 largest = lz_wave_reduce_max(myMax);
     const u64 anyMask = lz_ballot(any);
     const u32 topLane = 63u - lz_clz64(anyMask);               // n > 0 -> some symbol is present
@@ -400,16 +415,17 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
                 rank[k] += (ct > c4[k] || (ct == c4[k] && t < s)) ? 1u : 0u;
             }
         }
-        lz_wave_sync();
+        lz_lds_sync();
         for (u32 i = lane; i < 514u; i += 64u) ws[LZ_HUF_WS_NODECNT + i] = 0;
         for (u32 i = lane; i < 256u; i += 64u) ((u32*)parent)[i] = 0;
         for (u32 i = lane; i < 128u; i += 64u) { ((u32*)nbyte)[i] = 0; ((u32*)nbits)[i] = 0; }
-        lz_wave_sync();
+        lz_lds_sync();
         for (u32 k = 0; k < 4u; k++) {
             const u32 s = lane * 4u + k;
             if (s <= maxSym) { nodeCnt[rank[k]] = c4[k]; nbyte[rank[k]] = (u8)s; }
         }
-        lz_wave_sync();
+        lz_lds_sync();
+        LZ_HPROF(9);                                           // rank sort
         // ---- lane 0: tree, depth limit, canonical codes, weight header ----
         u32 hdr = 0;                                           // header size, 0 = reference error -> raw (lane 0's value,
                                                                // broadcast through LDS: fse[159])
@@ -460,8 +476,9 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
             }
             fse[159] = hdr;
         }
-        lz_wave_sync();
+        lz_lds_sync();
         hdr = lz_uniform(fse[159]);
+        LZ_HPROF(10);                                          // lane-0 tree / codes / header
         if (hdr != 0 && hdr + 12u < n) {                       // :556
             // ---- exact stream sizes: sum of code lengths per segment (huf_compress.c:473-513) ----
             const u32 seg = (n + 3u) / 4u;
@@ -474,6 +491,7 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
                 segBytes[k] = (bits + 1u + 7u) >> 3;
                 tot += segBytes[k];
             }
+            LZ_HPROF(11);                                      // exact sizes
             if (tot < n - 1u && tot + tot / 8u + 512u < n) {   // :570 and lizard_compress.c:157
                 if (lane == 0) {
                     lz_st16(payload + hdr, segBytes[0]); lz_st16(payload + hdr + 2, segBytes[1]); lz_st16(payload + hdr + 4, segBytes[2]);
@@ -486,6 +504,7 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
                     q += segBytes[k];
                 }
                 csize = tot; accept = true;
+                LZ_HPROF(12);                                  // bit packing
             }
         }
     }

@@ -86,22 +86,33 @@ LZ_DEV void lz_lds_atomic_add(u32* p, u32 v) { atomicAdd(p, v); }
 LZ_DEV void lz_lds_atomic_or(u32* p, u32 v) { atomicOr(p, v); }
 
 // Wave-wide reductions / exclusive prefix sum over all 64 lanes (every lane must call).
-LZ_DEV u32 lz_wave_reduce_add(u32 v)
+// DPP form (no LDS round trips): Hillis-Steele inside each row of 16 lanes with row_shr:1/2/4/8, then the
+// two row broadcasts that carry a row's total into the following rows (row_bcast:15 to rows 1 and 3,
+// row_bcast:31 to rows 2 and 3).  Lanes whose DPP source does not exist keep `old` = the identity 0.
+template <int CTRL, int ROW_MASK>
+LZ_DEV u32 lz_dpp0(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false); }
+LZ_DEV u32 lz_wave_scan_incl_add(u32 v)
 {
-    for (u32 d = 32; d > 0; d >>= 1) v += lz_shfl(v, lz_lane() ^ d);
-    return lz_uniform(v);
+    v += lz_dpp0<0x111, 0xf>(v);      // row_shr:1
+    v += lz_dpp0<0x112, 0xf>(v);      // row_shr:2
+    v += lz_dpp0<0x114, 0xf>(v);      // row_shr:4
+    v += lz_dpp0<0x118, 0xf>(v);      // row_shr:8
+    v += lz_dpp0<0x142, 0xa>(v);      // row_bcast:15 -> rows 1, 3
+    v += lz_dpp0<0x143, 0xc>(v);      // row_bcast:31 -> rows 2, 3
+    return v;
 }
-LZ_DEV u32 lz_wave_reduce_max(u32 v)
+LZ_DEV u32 lz_wave_scan_excl_add(u32 v) { return lz_wave_scan_incl_add(v) - v; }
+LZ_DEV u32 lz_wave_reduce_add(u32 v) { return lz_readlane(lz_wave_scan_incl_add(v), 63u); }
+LZ_DEV u32 lz_wave_reduce_max(u32 v)  // running max of unsigned values (identity 0), total in lane 63
 {
-    for (u32 d = 32; d > 0; d >>= 1) { const u32 o = lz_shfl(v, lz_lane() ^ d); v = o > v ? o : v; }
-    return lz_uniform(v);
-}
-LZ_DEV u32 lz_wave_scan_excl_add(u32 v)
-{
-    const u32 lane = lz_lane();
-    u32 incl = v;
-    for (u32 d = 1; d < 64; d <<= 1) { const u32 o = lz_shfl(incl, lane - d); if (lane >= d) incl += o; }
-    return incl - v;
+    u32 o;
+    o = lz_dpp0<0x111, 0xf>(v); v = o > v ? o : v;
+    o = lz_dpp0<0x112, 0xf>(v); v = o > v ? o : v;
+    o = lz_dpp0<0x114, 0xf>(v); v = o > v ? o : v;
+    o = lz_dpp0<0x118, 0xf>(v); v = o > v ? o : v;
+    o = lz_dpp0<0x142, 0xa>(v); v = o > v ? o : v;
+    o = lz_dpp0<0x143, 0xc>(v); v = o > v ? o : v;
+    return lz_readlane(v, 63u);
 }
 
 // Unaligned little-endian loads/stores from global memory.  gfx950 global/flat accesses have no

@@ -117,11 +117,13 @@ int main(int argc, char** argv)
                    (double)nb * bs / (ms * 1e-3) / 1e9, tot ? (double)nb * bs / tot : 0.0);
             {   /* instrumented library variant only (LD_LIBRARY_PATH=lizard_amd/variants/prof) */
                 int (*dump)(unsigned long long*) = (int (*)(unsigned long long*))dlsym(RTLD_DEFAULT, "LizardGPU_profileDump");
-                unsigned long long pr[8];
+                unsigned long long pr[16];
                 if (dump && dump(pr) == 0) {
                     static const char* nm[8] = { "roundA(bytes,hash,LDS,filter)", "roundB(cand wait,settle)", "extension", "glue+encode", "store drain", "container", "table init", "-" };
-                    double sum = 0; for (int k = 0; k < 8; k++) sum += (double)pr[k];
+                    double sum = 0; for (int k = 0; k < 8; k++) sum += (double)pr[k];   /* slots 8.. are sub-phases of the container slot */
                     for (int k = 0; k < 7; k++) printf("    prof %-32s %6.2f %%  %.3g clk\n", nm[k], 100.0 * pr[k] / sum, (double)pr[k]);
+                    {   static const char* hn[7] = { "huf histogram", "huf rank sort", "huf lane-0 tree/codes/header", "huf exact sizes", "huf bit packing", "-", "huf entry" };
+                        for (int k = 8; k < 15; k++) if (pr[k]) printf("      (within container) %-28s %6.2f %%\n", hn[k - 8], 100.0 * pr[k] / sum); }
                 }
             }
             fflush(stdout);
