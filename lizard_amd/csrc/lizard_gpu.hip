@@ -23,49 +23,52 @@ struct LzBatch {
     u8* scratch;    u32* counter;
 };
 
-// level 10/30 parser: the 2^12-slot hash table (24-bit slots, 12 KiB) is the only LDS the parser needs
-// -> 13 waves per CU; level 30 adds the Huffman stage's workspace.
+// Residency by construction.  LDS is what limits the number of blocks in flight, and the hardware hands it
+// out in 512-byte granules per WORKGROUP: thirteen independent 64-thread workgroups of 12 560 B each get
+// 12 800 B apiece, so only twelve fit in a CU's 160 KiB (the occupancy API, which divides raw sizes, says
+// thirteen).  Instead ONE workgroup per CU carries W independent waves and declares W private slices
+// of one allocation: 13 x 12 548 B = 163 124 B (level 10), 9 x 17 932 B (level 30), 3 x 53 252 B /
+// 3 x 54 540 B (levels 21 / 41) — 98.5-99.9 % of the CU's LDS.  The waves never synchronise with each other
+// (no s_barrier anywhere); each claims blocks from the device counter on its own.
 #ifndef LZ_EXP_HASHLOG
 #define LZ_EXP_HASHLOG 12     // experiment knob (timing only: any other value changes the output)
 #endif
-template <bool HUF>
-__global__ __launch_bounds__(64) void lz_fast12_kernel(LzBatch a)
+#define LZ_WAVES_FAST      13
+#define LZ_WAVES_FAST_HUF  9
+#define LZ_WAVES_PF        3
+
+template <int PARSER, int HASHLOG, int AUX, bool HUF, int W, int WSWORDS>
+__device__ __forceinline__ void lz_wave_main(const LzBatch& a)
 {
-    __shared__ u32 table[LZ_TAB_BYTES(LZ_EXP_HASHLOG) / 4u];
-    __shared__ u64 seqRing[LZ_SEQ_RING];
-    __shared__ u32 tagws[HUF ? LZ_HUF_WS_WORDS : 1u];
-    u8* tag = (u8*)tagws;
-    u8* scratch = a.scratch + (u64)blockIdx.x * LZ_SCRATCH_BYTES;
+    struct Slice { u32 table[LZ_TAB_BYTES(HASHLOG) / 4u]; u64 ring[PARSER == LZ_PARSER_FAST ? LZ_SEQ_RING : 1]; u32 ws[WSWORDS]; };
+    __shared__ Slice lds[W];
+    const u32 wave = threadIdx.x >> 6;
+    Slice& my = lds[wave];
+    u8* scratch = a.scratch + ((u64)blockIdx.x * W + wave) * LZ_SCRATCH_BYTES;
     for (;;) {
         lz_converge();
         const u32 b = lz_claim_index(a.counter);
         if (b >= a.nBlocks) break;
         const u32 n = (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
-        const u32 c = lz_compress_block<LZ_PARSER_FAST, LZ_EXP_HASHLOG, 0, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
-                                                     a.level, table, tag, scratch, seqRing);
+        const u32 c = lz_compress_block<PARSER, HASHLOG, AUX, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
+                                                                  a.level, my.table, (u8*)my.ws, scratch, my.ring);
         if (lz_lane() == 0) a.sizes[b] = c;
         lz_converge();
     }
 }
 
-// level 21/41 parser (priceFast + LIZv1): 2^14-entry table = 64 KiB of LDS per wave -> 2 waves per CU.
+// levels 10 / 30: fastSmall parser, 2^12-slot table (24-bit slots, 12 KiB) + sequence ring (+ Huffman workspace)
 template <bool HUF>
-__global__ __launch_bounds__(64) void lz_pricefast14_kernel(LzBatch a)
+__global__ __launch_bounds__(64 * (HUF ? LZ_WAVES_FAST_HUF : LZ_WAVES_FAST)) void lz_fast12_kernel(LzBatch a)
 {
-    __shared__ u32 table[1u << 14];
-    __shared__ u32 tagws[HUF ? LZ_HUF_WS_WORDS : 1024u];
-    u8* tag = (u8*)tagws;
-    u8* scratch = a.scratch + (u64)blockIdx.x * LZ_SCRATCH_BYTES;
-    for (;;) {
-        lz_converge();
-        const u32 b = lz_claim_index(a.counter);
-        if (b >= a.nBlocks) break;
-        const u32 n = (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
-        const u32 c = lz_compress_block<LZ_PARSER_PRICEFAST, 14, 12, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
-                                                                        a.level, table, tag, scratch, nullptr);
-        if (lz_lane() == 0) a.sizes[b] = c;
-        lz_converge();
-    }
+    lz_wave_main<LZ_PARSER_FAST, LZ_EXP_HASHLOG, 0, HUF, (HUF ? LZ_WAVES_FAST_HUF : LZ_WAVES_FAST), (HUF ? LZ_HUF_WS_WORDS : 1)>(a);
+}
+
+// levels 21 / 41: priceFast + LIZv1, 2^14-slot table (24-bit slots, 48 KiB) + round tag array / Huffman workspace
+template <bool HUF>
+__global__ __launch_bounds__(64 * LZ_WAVES_PF) void lz_pricefast14_kernel(LzBatch a)
+{
+    lz_wave_main<LZ_PARSER_PRICEFAST, 14, 12, HUF, LZ_WAVES_PF, (HUF ? LZ_HUF_WS_WORDS : 1024)>(a);
 }
 
 // synthetic input: one thread per block, block b = RDG_genBuffer(blockSize, P, seed0 + b)
@@ -119,21 +122,10 @@ int ctx_init_locked()
     LZ_HIP(hipSetDevice(g_want_device));
     hipDeviceProp_t prop;
     LZ_HIP(hipGetDeviceProperties(&prop, g_want_device));
-    int perCu = 0, perCuHuf = 0;
-    LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, lz_fast12_kernel<false>, 64, 0));
-    LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuHuf, lz_fast12_kernel<true>, 64, 0));
-    int perCuPf = 0, perCuPfHuf = 0;
-    LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuPf, lz_pricefast14_kernel<false>, 64, 0));
-    LZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuPfHuf, lz_pricefast14_kernel<true>, 64, 0));
-    if (perCu < 1) perCu = 1;
-    if (perCuHuf < 1) perCuHuf = 1;
-    if (perCuPf < 1) perCuPf = 1;
-    if (perCuPfHuf < 1) perCuPfHuf = 1;
     g_ctx.cus = prop.multiProcessorCount;
-    g_ctx.waves = g_ctx.cus * perCu;
-    g_ctx.wavesHuf = g_ctx.cus * perCuHuf;
-    g_ctx.wavesPf = g_ctx.cus * perCuPf;
-    g_ctx.wavesPfHuf = g_ctx.cus * perCuPfHuf;
+    g_ctx.waves = g_ctx.cus * LZ_WAVES_FAST;             // one workgroup per CU, W waves each (see lz_wave_main)
+    g_ctx.wavesHuf = g_ctx.cus * LZ_WAVES_FAST_HUF;
+    g_ctx.wavesPf = g_ctx.wavesPfHuf = g_ctx.cus * LZ_WAVES_PF;
     LZ_HIP(hipMalloc((void**)&g_ctx.scratch, (size_t)g_ctx.waves * LZ_SCRATCH_BYTES));
 #ifdef LZ_PROFILE
     LZ_HIP(hipMemset(g_ctx.scratch, 0, (size_t)g_ctx.waves * LZ_SCRATCH_BYTES));
@@ -153,6 +145,10 @@ int launch_locked(const void* d_src, size_t nBlocks, size_t blockSize, size_t la
     if (!d_src || !d_dst || !d_sizes || nBlocks == 0 || nBlocks > 0xFFFFFFFFu) return -LIZARDGPU_ERR_ARG;
     if (blockSize == 0 || blockSize > LIZARD_MAX_INPUT_SIZE || lastBlockSize == 0 || lastBlockSize > blockSize) return -LIZARDGPU_ERR_ARG;
     if (dstStride < (size_t)LIZARD_COMPRESSBOUND((int)blockSize)) return -LIZARDGPU_ERR_ARG;
+    if ((level == 21 || level == 41) && blockSize >= (1u << 24) - 1u) {      // 24-bit table positions (lz_pricefast.h)
+        snprintf(g_ctx.err, sizeof g_ctx.err, "levels 21/41: blocks of 16 MiB or more are not supported on the GPU path");
+        return -LIZARDGPU_ERR_ARG;
+    }
     int rc = ctx_init_locked();
     if (rc) return rc;
     LzBatch a;
@@ -162,15 +158,17 @@ int launch_locked(const void* d_src, size_t nBlocks, size_t blockSize, size_t la
     int lv = level > LIZARD_MAX_CLEVEL ? LIZARD_MAX_CLEVEL : level;
     if (lv < LIZARD_MIN_CLEVEL) lv = LIZARD_DEFAULT_CLEVEL;
     a.level = (u32)lv;
-    const size_t resident = (size_t)(lv == 10 ? g_ctx.waves : lv == 30 ? g_ctx.wavesHuf : lv == 21 ? g_ctx.wavesPf : g_ctx.wavesPfHuf);
-    const u32 grid = (u32)(nBlocks < resident ? nBlocks : resident);
+    // one workgroup of W waves per CU; small batches launch only as many workgroups as they have blocks for
+    const u32 W = lv == 10 ? LZ_WAVES_FAST : lv == 30 ? LZ_WAVES_FAST_HUF : LZ_WAVES_PF;
+    u32 grid = (u32)((nBlocks + W - 1) / W);
+    if (grid > (u32)g_ctx.cus) grid = (u32)g_ctx.cus;
     LZ_HIP(hipMemsetAsync(g_ctx.counter, 0, 4, stream));
     LZ_HIP(hipEventRecord(g_ctx.ev0, stream));
     switch (lv) {
-    case 10: hipLaunchKernelGGL(lz_fast12_kernel<false>, dim3(grid), dim3(64), 0, stream, a); break;
-    case 30: hipLaunchKernelGGL(lz_fast12_kernel<true>, dim3(grid), dim3(64), 0, stream, a); break;
-    case 21: hipLaunchKernelGGL(lz_pricefast14_kernel<false>, dim3(grid), dim3(64), 0, stream, a); break;
-    default: hipLaunchKernelGGL(lz_pricefast14_kernel<true>, dim3(grid), dim3(64), 0, stream, a); break;
+    case 10: hipLaunchKernelGGL(lz_fast12_kernel<false>, dim3(grid), dim3(64 * LZ_WAVES_FAST), 0, stream, a); break;
+    case 30: hipLaunchKernelGGL(lz_fast12_kernel<true>, dim3(grid), dim3(64 * LZ_WAVES_FAST_HUF), 0, stream, a); break;
+    case 21: hipLaunchKernelGGL(lz_pricefast14_kernel<false>, dim3(grid), dim3(64 * LZ_WAVES_PF), 0, stream, a); break;
+    default: hipLaunchKernelGGL(lz_pricefast14_kernel<true>, dim3(grid), dim3(64 * LZ_WAVES_PF), 0, stream, a); break;
     }
     LZ_HIP(hipGetLastError());
     LZ_HIP(hipEventRecord(g_ctx.ev1, stream));

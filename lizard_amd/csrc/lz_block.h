@@ -592,7 +592,7 @@ LZ_DEV u32 lz_write_subblock_fast(const u8* src, u32 S, u32 E, u8* op, LzStreams
 // ---- one API block: reference Lizard_compress_extState on a zeroed state (lizard_compress.c:583) ----
 // dst must have room for Lizard_compressBound(n) bytes. Returns the compressed size (uniform).
 // seqRing:  fast parser -> LZ_SEQ_RING u64 of LDS (may be null for priceFast).
-// tableMem: fast parser -> LZ_TAB_BYTES(HASHLOG) bytes (24-bit slots, see LzTab); priceFast -> 4 << HASHLOG bytes.
+// tableMem: LZ_TAB_BYTES(HASHLOG) bytes (24-bit slots, see LzTab) for both parsers.
 // AUX:      priceFast only -> TAGLOG of the round tag array.
 // PARSER: 0 = fastSmall/fast + fastLZ4 codewords, 1 = priceFast + LIZv1 codewords.
 #define LZ_PARSER_FAST      0
@@ -608,9 +608,8 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
     for (int k = 0; k < 16; k++) st.prof[k] = 0;
 #endif
     LzTab tab = lz_tab_bind<HASHLOG>(tableMem);
-    u32* table = (u32*)tableMem;
     if constexpr (PARSER == LZ_PARSER_FAST) { lz_tab_sweep<HASHLOG>(tab, 0, true); st.sweepAt = 32768u; }
-    else for (u32 i = lane; i < (1u << HASHLOG); i += 64u) table[i] = LZ_EMPTY;
+    else for (u32 i = lane; i < (1u << HASHLOG); i += 64u) lz_tab_set(tab, i, LZ_EMPTY24);
     lz_wave_sync();
     LZ_PROF(st, 6);                                           // table init
     if (lane == 0) dst[0] = (u8)level;                        // lizard_compress.c:488
@@ -621,7 +620,7 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
         st.nlit = st.nflags = st.noff16 = st.noff24 = 0;      // Lizard_initBlock, :130-138
         st.nseq = 0; st.lastLits = 0;
         if constexpr (PARSER == LZ_PARSER_FAST) lz_parse_fast<HASHLOG>(src, pos, pos + part, tab, st);
-        else                                    lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, table, ws, st);
+        else                                    lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, tab, ws, st);
         if constexpr (PARSER == LZ_PARSER_FAST) op += lz_write_subblock_fast<HUF>(src, pos, pos + part, dst + op, st, (u32*)ws);
         else if constexpr (HUF)                 op += lz_write_subblock_huf(src + pos, part, dst + op, st, (u32*)ws);
         else                                    op += lz_write_subblock_raw_streams(src + pos, part, dst + op, st);

@@ -33,14 +33,14 @@
 #define LZ_HUF_DEFAULTLOG  11u    // HUF_TABLELOG_DEFAULT, huf.h:119
 
 // LDS workspace (u32 words). The node area and the packer's staging ring alias (disjoint in time).
-#define LZ_HUF_WS_COUNT    0u                          // u32 count[256]
-#define LZ_HUF_WS_CTAB     256u                        // u32 ctab[256]: val | nbBits << 16
-#define LZ_HUF_WS_NODECNT  512u                        // u32 nodeCount[1 + 512] (slot 0 = barrier node -1)
+#define LZ_HUF_WS_COUNT    0u                          // u32 count[256]; after the sort: weights (bytes 0..255) and,
+#define LZ_HUF_WS_FSE      96u                         //   from word 96 on, 160 words of FSE tables for the weight header
+#define LZ_HUF_WS_CTAB     256u                        // u16 ctab[256]: val | nbBits << 12
+#define LZ_HUF_WS_NODECNT  384u                        // u32 nodeCount[1 + 512] (slot 0 = barrier node -1)
 #define LZ_HUF_WS_PARENT   (LZ_HUF_WS_NODECNT + 514u)  // u16 parent[512]
-#define LZ_HUF_WS_BYTE     (LZ_HUF_WS_PARENT + 256u)   // u8 byte[512]
-#define LZ_HUF_WS_NBITS    (LZ_HUF_WS_BYTE + 128u)     // u8 nbBits[512]
-#define LZ_HUF_WS_FSE      (LZ_HUF_WS_NBITS + 128u)    // 160 words of FSE tables for the weight header
-#define LZ_HUF_WS_WORDS    (LZ_HUF_WS_FSE + 160u)
+#define LZ_HUF_WS_BYTE     (LZ_HUF_WS_PARENT + 256u)   // u8 byte[256] (leaves only)
+#define LZ_HUF_WS_NBITS    (LZ_HUF_WS_BYTE + 64u)      // u8 nbBits[512]
+#define LZ_HUF_WS_WORDS    (LZ_HUF_WS_NBITS + 128u)    // 1346 words = 5384 B
 #define LZ_HUF_WS_STAGE    LZ_HUF_WS_NODECNT           // packer staging ring (>= 100 words), aliases nodes
 #define LZ_HUF_STAGE_WORDS 104u
 
@@ -298,7 +298,7 @@ LZ_DEV u32 lz_huf_compress_weights(u8* dst, const u8* wt, u32 wtSize, u32* fse)
 
 // One 1X bitstream (huf_compress.c:427-470): symbols src[a..b) appended LAST -> FIRST, LSB first, then a
 // single '1'.  nbytes = ceil((bits+1)/8) is known from the size pass.  All lanes call; `stage` is LDS.
-LZ_DEV void lz_huf_pack_segment(const u8* src, u32 a, u32 b, u8* out, u32 nbytes, const u32* ctab, u32* stage)
+LZ_DEV void lz_huf_pack_segment(const u8* src, u32 a, u32 b, u8* out, u32 nbytes, const u16* ctab, u32* stage)
 {
     const u32 lane = lz_lane();
     for (u32 i = lane; i < LZ_HUF_STAGE_WORDS; i += 64u) stage[i] = 0;
@@ -316,8 +316,8 @@ LZ_DEV void lz_huf_pack_segment(const u8* src, u32 a, u32 b, u8* out, u32 nbytes
             const u32 hi = a + remaining - 1u - first;
             for (u32 j = 0; j < cnt; j++) {
                 const u32 e = ctab[src[hi - j]];
-                acc |= (u64)(e & 0xFFFFu) << len;
-                len += e >> 16;
+                acc |= (u64)(e & 0xFFFu) << len;
+                len += e >> 12;
             }
         }
         const u32 off = lz_wave_scan_excl_add(len);
@@ -365,7 +365,7 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
         return 3u + n;
     }
     u32* count = ws + LZ_HUF_WS_COUNT;
-    u32* ctab = ws + LZ_HUF_WS_CTAB;
+    u16* ctab = (u16*)(ws + LZ_HUF_WS_CTAB);
     u32* nodeCnt = ws + LZ_HUF_WS_NODECNT + 1;                 // nodeCnt[-1] = barrier
     u16* parent = (u16*)(ws + LZ_HUF_WS_PARENT);
     u8* nbyte = (u8*)(ws + LZ_HUF_WS_BYTE);
@@ -418,7 +418,7 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
         lz_lds_sync();
         for (u32 i = lane; i < 514u; i += 64u) ws[LZ_HUF_WS_NODECNT + i] = 0;
         for (u32 i = lane; i < 256u; i += 64u) ((u32*)parent)[i] = 0;
-        for (u32 i = lane; i < 128u; i += 64u) { ((u32*)nbyte)[i] = 0; ((u32*)nbits)[i] = 0; }
+        for (u32 i = lane; i < 128u; i += 64u) { if (i < 64u) ((u32*)nbyte)[i] = 0; ((u32*)nbits)[i] = 0; }
         lz_lds_sync();
         for (u32 k = 0; k < 4u; k++) {
             const u32 s = lane * 4u + k;
@@ -453,17 +453,17 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
             for (u32 i = nodeRoot - 1u; i >= START; i--) nbits[i] = (u8)(nbits[parent[i]] + 1u);
             for (u32 i = 0; i <= nonNull; i++) nbits[i] = (u8)(nbits[parent[i]] + 1u);
             huffLog = lz_huf_set_max_height(nodeCnt, nbits, nonNull, huffLog);   // :379
-            // canonical values (:381-398) -> ctab[symbol] = val | nbBits << 16
+            // canonical values (:381-398) -> ctab[symbol] = val | nbBits << 12  (val < 2^nbBits <= 2^12)
             u32 nbPerRank[LZ_HUF_MAXBITS + 1], valPerRank[LZ_HUF_MAXBITS + 1];
             for (u32 i = 0; i <= LZ_HUF_MAXBITS; i++) { nbPerRank[i] = 0; valPerRank[i] = 0; }
             for (u32 i = 0; i <= nonNull; i++) nbPerRank[nbits[i]]++;
             { u32 mn = 0; for (u32 i = huffLog; i > 0; i--) { valPerRank[i] = mn; mn = (mn + nbPerRank[i]) & 0xFFFFu; mn >>= 1; } }
             for (u32 i = 0; i < 256u; i++) ctab[i] = 0;
-            for (u32 i = 0; i <= maxSym; i++) ctab[nbyte[i]] = (u32)nbits[i] << 16;
-            for (u32 s = 0; s <= maxSym; s++) { const u32 nb = ctab[s] >> 16; ctab[s] |= (valPerRank[nb]++) & 0xFFFFu; }
+            for (u32 i = 0; i <= maxSym; i++) ctab[nbyte[i]] = (u16)((u32)nbits[i] << 12);
+            for (u32 s = 0; s <= maxSym; s++) { const u32 nb = ctab[s] >> 12; ctab[s] = (u16)(ctab[s] | ((valPerRank[nb]++) & 0xFFFu)); }
             // HUF_writeCTable (:132-165): weights of symbols 0..maxSym-1 into count[] (free now), as bytes
             u8* wt = (u8*)count;
-            for (u32 s = 0; s < maxSym; s++) { const u32 nb = ctab[s] >> 16; wt[s] = nb ? (u8)(huffLog + 1u - nb) : 0; }
+            for (u32 s = 0; s < maxSym; s++) { const u32 nb = ctab[s] >> 12; wt[s] = nb ? (u8)(huffLog + 1u - nb) : 0; }
             const u32 h = lz_huf_compress_weights(payload + 1, wt, maxSym, fse);
             if (h == 0xFFFFFFFFu) hdr = 0;
             else if (h > 1u && h < maxSym / 2u) { payload[0] = (u8)h; hdr = h + 1u; }
@@ -486,7 +486,7 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
             for (u32 k = 0; k < 4u; k++) {
                 const u32 a = k * seg, b = (k == 3u) ? n : (k + 1u) * seg;
                 u32 bits = 0;
-                for (u32 i = a + lane; i < b; i += 64u) bits += ctab[stream[i]] >> 16;
+                for (u32 i = a + lane; i < b; i += 64u) bits += (u32)ctab[stream[i]] >> 12;
                 bits = lz_wave_reduce_add(bits);
                 segBytes[k] = (bits + 1u + 7u) >> 3;
                 tot += segBytes[k];

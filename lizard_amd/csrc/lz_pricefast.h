@@ -67,8 +67,12 @@ LZ_DEV void lz_emit_lizv1(const u8* src, u32 anchor, u32 P, u32 ml, u32 M, LzStr
 
 // Sub-block [S,E) of the block at src. windowLog 22 / minMatchLongOff 16 are the level-21/22 values
 // (lizard_common.h:249-250).  table: 2^HASHLOG positions (LZ_EMPTY = never written); tag: 2^TAGLOG bytes.
+// Table: 2^HASHLOG slots of 24 bits (u16 + u8 arrays, LzTab without check bits) holding block-relative
+// positions, LZ_EMPTY24 when never written: 48 KiB of LDS at HASHLOG 14 instead of 64 KiB -> 3 waves per CU.
+// Positions must stay below 2^24 - 1: blocks up to 16 MiB (the launcher refuses larger ones at these levels).
+#define LZ_EMPTY24 0xFFFFFFu
 template <int HASHLOG, int TAGLOG>
-LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, u32* table, u8* tag, LzStreams& st)
+LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const LzTab& table, u8* tag, LzStreams& st)
 {
     const u32 lane = lz_lane();
     const u64 laneBit = 1ull << lane;
@@ -87,12 +91,12 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, u32* table, u8* tag,
             const u32 p = ip + lane;
             const bool valid = p < mflimit;
             const u32 lowPos = p > maxDist ? p - maxDist : 0u;   // pricefast.h:11-13, per probe
-            u32 h = 0, e = LZ_EMPTY, first4 = 0;
+            u32 h = 0, e = LZ_EMPTY24, first4 = 0;
             if (valid) {
                 const u64 bytes = lz_ld64(src + p);
                 first4 = (u32)bytes;
                 h = lz_hash5<HASHLOG>(bytes);
-                e = table[h];                                    // pricefast.h:160,168 (old value)
+                e = lz_tab_get(table, h);                        // pricefast.h:160,168 (old value)
                 tag[h & ((1u << TAGLOG) - 1u)] = (u8)lane;
             }
             lz_wave_sync();
@@ -132,7 +136,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, u32* table, u8* tag,
             u32 w = 0;
             u64 commit = validMask;
             if (okMask) { w = lz_ctz64(okMask); commit = validMask & (~0ull >> (63u - w)); }
-            if ((commit & laneBit) && (grp & commit & ~(lanesBelow | laneBit)) == 0) table[h] = tAfter;
+            if ((commit & laneBit) && (grp & commit & ~(lanesBelow | laneBit)) == 0) lz_tab_set(table, h, tAfter);
             lz_wave_sync();
             if (okMask) {
                 P = lz_readlane(p, w);
@@ -156,7 +160,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, u32* table, u8* tag,
             start2 = ip + ml - 2u;
             {
                 const u32 h2 = lz_hash5<HASHLOG>(lz_ld64(src + start2));
-                const u32 e2 = table[h2];
+                const u32 e2 = lz_tab_get(table, h2);
                 const u32 low2 = start2 > maxDist ? start2 - maxDist : 0u;
                 ml2 = 0;
                 if (e2 < start2 && e2 >= low2 && start2 - e2 >= LZ_MIN_OFFSET && lz_ld32(src + e2) == lz_ld32(src + start2)) {   // :106-110
@@ -164,7 +168,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, u32* table, u8* tag,
                     if (mlt >= LZ_MM_LONGOFF || start2 - e2 < LZ_16BIT_OFFSET) { ml2 = mlt; ref2 = e2; }       // :112
                 }
                 lz_wave_sync();
-                if (lane == 0 && (e2 >= start2 || start2 >= e2 + LZ_MIN_OFFSET)) table[h2] = start2;         // :190-191
+                if (lane == 0 && (e2 >= start2 || start2 >= e2 + LZ_MIN_OFFSET)) lz_tab_set(table, h2, start2);   // :190-191
                 lz_wave_sync();
             }
             if (!ml2) goto encode;
