@@ -73,7 +73,8 @@ enum {
     LIZARDGPU_ERR_NOMEM = 5
 };
 
-/* 1 if `compressionLevel` (after the reference's clamp, lib/lizard_compress.c:303-308) runs on the GPU. */
+/* 1 if `compressionLevel` (after the reference's clamp, lib/lizard_compress.c:303-308) runs on the GPU:
+ * 10, 30 (fastSmall), 11, 31 (fast, blocks <= 4 MiB), 21, 41 (priceFast, blocks < 16 MiB), 30/31/41 with huff0. */
 int LizardGPU_levelSupported(int compressionLevel);
 
 /* Select the HIP device used by this process for subsequent calls (default: current device 0).

@@ -21,6 +21,7 @@ struct LzBatch {
     const u8* src;  u64 blockSize;  u32 nBlocks;  u32 lastBlockSize;
     u8* dst;        u64 dstStride;  u32* sizes;   u32 level;
     u8* scratch;    u32* counter;
+    u8* tables;     // levels 11/31: one LZ_TABWIDE_BYTES(18) hash table per resident wave (global memory)
 };
 
 // Residency by construction.  LDS is what limits the number of blocks in flight, and the hardware hands it
@@ -40,18 +41,21 @@ struct LzBatch {
 template <int PARSER, int HASHLOG, int AUX, bool HUF, int W, int WSWORDS>
 __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
 {
-    struct Slice { u32 table[LZ_TAB_BYTES(HASHLOG) / 4u]; u64 ring[PARSER == LZ_PARSER_FAST ? LZ_SEQ_RING : 1]; u32 ws[WSWORDS]; };
+    constexpr bool kGlobalTable = HASHLOG > 14;                      // hashLog 18 (levels 11/31): 1 MiB per wave, not LDS
+    struct Slice { u32 table[kGlobalTable ? 1 : LZ_TAB_BYTES(HASHLOG) / 4u]; u64 ring[PARSER == LZ_PARSER_FAST ? LZ_SEQ_RING : 1]; u32 ws[WSWORDS]; };
     __shared__ Slice lds[W];
     const u32 wave = threadIdx.x >> 6;
     Slice& my = lds[wave];
-    u8* scratch = a.scratch + ((u64)blockIdx.x * W + wave) * LZ_SCRATCH_BYTES;
+    const u64 slot = (u64)blockIdx.x * W + wave;
+    u8* scratch = a.scratch + slot * LZ_SCRATCH_BYTES;
+    void* tableMem = kGlobalTable ? (void*)(a.tables + slot * LZ_TABWIDE_BYTES(18)) : (void*)my.table;
     for (;;) {
         lz_converge();
         const u32 b = lz_claim_index(a.counter);
         if (b >= a.nBlocks) break;
         const u32 n = (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
         const u32 c = lz_compress_block<PARSER, HASHLOG, AUX, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
-                                                                  a.level, my.table, (u8*)my.ws, scratch, my.ring);
+                                                                  a.level, tableMem, (u8*)my.ws, scratch, my.ring);
         if (lz_lane() == 0) a.sizes[b] = c;
         lz_converge();
     }
@@ -62,6 +66,14 @@ template <bool HUF>
 __global__ __launch_bounds__(64 * (HUF ? LZ_WAVES_FAST_HUF : LZ_WAVES_FAST)) void lz_fast12_kernel(LzBatch a)
 {
     lz_wave_main<LZ_PARSER_FAST, LZ_EXP_HASHLOG, 0, HUF, (HUF ? LZ_WAVES_FAST_HUF : LZ_WAVES_FAST), (HUF ? LZ_HUF_WS_WORDS : 1)>(a);
+}
+
+// levels 11 / 31: fast parser, 2^18-slot table (u32 slots, 1 MiB per wave in global memory: L2 / Infinity Cache)
+#define LZ_WAVES_FAST18 16
+template <bool HUF>
+__global__ __launch_bounds__(64 * LZ_WAVES_FAST18) void lz_fast18_kernel(LzBatch a)
+{
+    lz_wave_main<LZ_PARSER_FAST, 18, 0, HUF, LZ_WAVES_FAST18, (HUF ? LZ_HUF_WS_WORDS : 1)>(a);
 }
 
 // levels 21 / 41: priceFast + LIZv1, 2^14-slot table (24-bit slots, 48 KiB) + round tag array / Huffman workspace
@@ -86,6 +98,7 @@ struct Ctx {
     int   waves = 0;            // persistent grid size (level 10)
     int   wavesHuf = 0;         // persistent grid size (level 30: larger LDS workspace)
     int   wavesPf = 0, wavesPfHuf = 0;   // levels 21 / 41
+    u8*   tables = nullptr;     // levels 11 / 31, allocated on first use
     u8*   scratch = nullptr;
     u32*  counter = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -123,7 +136,7 @@ int ctx_init_locked()
     hipDeviceProp_t prop;
     LZ_HIP(hipGetDeviceProperties(&prop, g_want_device));
     g_ctx.cus = prop.multiProcessorCount;
-    g_ctx.waves = g_ctx.cus * LZ_WAVES_FAST;             // one workgroup per CU, W waves each (see lz_wave_main)
+    g_ctx.waves = g_ctx.cus * LZ_WAVES_FAST18;            // scratch slots for the largest W (one workgroup per CU, see lz_wave_main)
     g_ctx.wavesHuf = g_ctx.cus * LZ_WAVES_FAST_HUF;
     g_ctx.wavesPf = g_ctx.wavesPfHuf = g_ctx.cus * LZ_WAVES_PF;
     LZ_HIP(hipMalloc((void**)&g_ctx.scratch, (size_t)g_ctx.waves * LZ_SCRATCH_BYTES));
@@ -154,12 +167,22 @@ int launch_locked(const void* d_src, size_t nBlocks, size_t blockSize, size_t la
     LzBatch a;
     a.src = (const u8*)d_src; a.blockSize = blockSize; a.nBlocks = (u32)nBlocks; a.lastBlockSize = (u32)lastBlockSize;
     a.dst = (u8*)d_dst; a.dstStride = dstStride; a.sizes = d_sizes; a.level = (u32)level;
-    a.scratch = g_ctx.scratch; a.counter = g_ctx.counter;
+    a.scratch = g_ctx.scratch; a.counter = g_ctx.counter; a.tables = g_ctx.tables;
     int lv = level > LIZARD_MAX_CLEVEL ? LIZARD_MAX_CLEVEL : level;
     if (lv < LIZARD_MIN_CLEVEL) lv = LIZARD_DEFAULT_CLEVEL;
     a.level = (u32)lv;
     // one workgroup of W waves per CU; small batches launch only as many workgroups as they have blocks for
-    const u32 W = lv == 10 ? LZ_WAVES_FAST : lv == 30 ? LZ_WAVES_FAST_HUF : LZ_WAVES_PF;
+    const u32 W = lv == 10 ? LZ_WAVES_FAST : lv == 30 ? LZ_WAVES_FAST_HUF : (lv == 11 || lv == 31) ? LZ_WAVES_FAST18 : LZ_WAVES_PF;
+    if (lv == 11 || lv == 31) {
+        if (blockSize > (4u << 20)) {
+            snprintf(g_ctx.err, sizeof g_ctx.err, "levels 11/31: blocks above 4 MiB are not supported on the GPU path");
+            return -LIZARDGPU_ERR_ARG;
+        }
+        if (!g_ctx.tables) {
+            LZ_HIP(hipMalloc((void**)&g_ctx.tables, (size_t)g_ctx.cus * LZ_WAVES_FAST18 * LZ_TABWIDE_BYTES(18)));
+            a.tables = g_ctx.tables;
+        }
+    }
     u32 grid = (u32)((nBlocks + W - 1) / W);
     if (grid > (u32)g_ctx.cus) grid = (u32)g_ctx.cus;
     LZ_HIP(hipMemsetAsync(g_ctx.counter, 0, 4, stream));
@@ -167,6 +190,8 @@ int launch_locked(const void* d_src, size_t nBlocks, size_t blockSize, size_t la
     switch (lv) {
     case 10: hipLaunchKernelGGL(lz_fast12_kernel<false>, dim3(grid), dim3(64 * LZ_WAVES_FAST), 0, stream, a); break;
     case 30: hipLaunchKernelGGL(lz_fast12_kernel<true>, dim3(grid), dim3(64 * LZ_WAVES_FAST_HUF), 0, stream, a); break;
+    case 11: hipLaunchKernelGGL(lz_fast18_kernel<false>, dim3(grid), dim3(64 * LZ_WAVES_FAST18), 0, stream, a); break;
+    case 31: hipLaunchKernelGGL(lz_fast18_kernel<true>, dim3(grid), dim3(64 * LZ_WAVES_FAST18), 0, stream, a); break;
     case 21: hipLaunchKernelGGL(lz_pricefast14_kernel<false>, dim3(grid), dim3(64 * LZ_WAVES_PF), 0, stream, a); break;
     default: hipLaunchKernelGGL(lz_pricefast14_kernel<true>, dim3(grid), dim3(64 * LZ_WAVES_PF), 0, stream, a); break;
     }
@@ -194,7 +219,7 @@ int LizardGPU_levelSupported(int level)
 {
     if (level > LIZARD_MAX_CLEVEL) level = LIZARD_MAX_CLEVEL;        // reference lizard_compress.c:303-308
     if (level < LIZARD_MIN_CLEVEL) level = LIZARD_DEFAULT_CLEVEL;
-    return level == 10 || level == 30 || level == 21 || level == 41;
+    return level == 10 || level == 30 || level == 11 || level == 31 || level == 21 || level == 41;
 }
 
 int LizardGPU_setDevice(int device)
@@ -211,7 +236,7 @@ int LizardGPU_residentWaves(void)
 {
     pthread_mutex_lock(&g_mu);
     int rc = ctx_init_locked();
-    int w = rc ? rc : g_ctx.waves;
+    int w = rc ? rc : g_ctx.cus * LZ_WAVES_FAST;      // level-10 residency (13 waves per CU)
     pthread_mutex_unlock(&g_mu);
     return w;
 }

@@ -278,22 +278,53 @@ LZ_DEV void lz_emit_last_literals(const u8* src, u32 anchor, u32 E, LzStreams& s
 //                the probing position's cannot pass the reference's 4-byte equality test (fast.h:97), so
 //                its bytes are never fetched: most rounds issue no candidate gather at all.  Equal check
 //                bits prove nothing; those lanes still load and compare the real bytes.
-struct LzTab { u16* lo; u8* hi; };
+struct LzTab {
+    u16* lo; u8* hi;
+    static constexpr bool kSweeps = true;
+    LZ_DEVM u32  entry(u32 p, u32 first4) const { return (p & 0x1FFFFu) | ((first4 * 2654435761u) >> 25 << 17); }
+    LZ_DEVM u32  get(u32 h) const { return (u32)lo[h] | ((u32)hi[h] << 16); }
+    LZ_DEVM void set(u32 h, u32 ent) const { lo[h] = (u16)ent; hi[h] = (u8)(ent >> 16); }
+    // age of a slot seen from position p (0..131071); usable iff 8 <= age <= 65535 (+ the lowLimit rule)
+    LZ_DEVM u32  age(u32 p, u32 ent) const { return (p - ent) & 0x1FFFFu; }
+    LZ_DEVM bool sameCheck(u32 a, u32 b) const { return ((a ^ b) >> 17) == 0; }
+    // positions of one round differ by < 2^16, so the low halves alone tell the writers of a slot apart
+    LZ_DEVM bool lostPut(u32 h, u32 mine) const { return lo[h] != (u16)mine; }
+    LZ_DEVM void sync() const { lz_lds_sync(); }
+};
 // One extra slot (index 2^HASHLOG, "trash") lets lanes that must not store do so anyway, branch-free.
 #define LZ_TAB_BYTES(HASHLOG) ((3u << (HASHLOG)) + 4u)
 template <int HASHLOG> LZ_DEV LzTab lz_tab_bind(void* mem) { LzTab t; t.lo = (u16*)mem; t.hi = (u8*)mem + (2u << HASHLOG) + 2u; return t; }
-LZ_DEV u32 lz_tab_entry(u32 p, u32 first4) { return (p & 0x1FFFFu) | ((first4 * 2654435761u) >> 25 << 17); }
-LZ_DEV u32 lz_tab_get(const LzTab& t, u32 h) { return (u32)t.lo[h] | ((u32)t.hi[h] << 16); }
-LZ_DEV void lz_tab_set(const LzTab& t, u32 h, u32 ent) { t.lo[h] = (u16)ent; t.hi[h] = (u8)(ent >> 16); }
-// age of a slot seen from position p (0..131071); usable iff 8 <= age <= 65535 (+ the lowLimit rule)
-LZ_DEV u32 lz_tab_age(u32 p, u32 ent) { return (p - ent) & 0x1FFFFu; }
-// Re-stamp every slot that is dead at position Ps (age >= 65536); with Ps = 0 on a fresh table: all empty.
+LZ_DEV u32 lz_tab_get(const LzTab& t, u32 h) { return t.get(h); }
+LZ_DEV void lz_tab_set(const LzTab& t, u32 h, u32 ent) { t.set(h, ent); }
+// Re-stamp every slot that is dead at position Ps (age >= 65536); with `fresh`: all empty.
 template <int HASHLOG>
 LZ_DEV void lz_tab_sweep(const LzTab& t, u32 Ps, bool fresh)
 {
     const u32 dead = (Ps + 65536u) & 0x1FFFFu;
     for (u32 i = lz_lane(); i < (1u << HASHLOG); i += 64u)
-        if (fresh || lz_tab_age(Ps, lz_tab_get(t, i)) >= 65536u) lz_tab_set(t, i, dead);
+        if (fresh || t.age(Ps, t.get(i)) >= 65536u) t.set(i, dead);
+}
+template <int HASHLOG> LZ_DEV void lz_tab_fresh(const LzTab& t) { lz_tab_sweep<HASHLOG>(t, 0, true); }
+
+// Wide variant for tables that do not fit LDS (hashLog 18: levels 11/31; 1 MiB per wave in global memory,
+// L2/Infinity-Cache resident): u32 slots, bits 0..21 = position (blocks up to 4 MiB), bits 22..31 = check
+// hash, 0xFFFFFFFF = empty.  Full positions need no sweep; cross-lane ordering needs the full wave sync.
+struct LzTabWide {
+    u32* w;
+    static constexpr bool kSweeps = false;
+    LZ_DEVM u32  entry(u32 p, u32 first4) const { return p | ((first4 * 2654435761u) >> 22 << 22); }
+    LZ_DEVM u32  get(u32 h) const { return w[h]; }
+    LZ_DEVM void set(u32 h, u32 ent) const { w[h] = ent; }
+    LZ_DEVM u32  age(u32 p, u32 ent) const { return p - (ent & 0x3FFFFFu); }     // empty / not-before-p slots wrap to > 65535
+    LZ_DEVM bool sameCheck(u32 a, u32 b) const { return ((a ^ b) >> 22) == 0; }
+    LZ_DEVM bool lostPut(u32 h, u32 mine) const { return w[h] != mine; }
+    LZ_DEVM void sync() const { lz_wave_sync(); }
+};
+#define LZ_TABWIDE_BYTES(HASHLOG) ((4u << (HASHLOG)) + 64u)
+template <int HASHLOG> LZ_DEV void lz_tab_fresh(const LzTabWide& t)
+{
+    uint4 ff; ff.x = ff.y = ff.z = ff.w = 0xFFFFFFFFu;
+    for (u32 i = lz_lane() * 4u; i < (1u << HASHLOG) + 4u; i += 256u) *(uint4*)(t.w + i) = ff;   // 16 B per lane, aligned base
 }
 
 // Position handled by `slot` of the current run.  A run that follows a match ("special") spends its first
@@ -317,8 +348,8 @@ LZ_DEV void lz_slot_pos(u32 ip, u32 special, u32 slot, u32 mflimit, u32& p, bool
 //   * lanes whose candidate survives the check bits fetch, in one batch, everything the winner needs:
 //     16 bytes forward at candidate and position (resolves match lengths < 16 without another trip)
 //     and 8 bytes backward (resolves backward extensions < 8).
-template <int HASHLOG>
-LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const LzTab& table, LzStreams& st)
+template <int HASHLOG, class TAB>
+LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStreams& st)
 {
     const u32 lane = lz_lane();
     const u64 laneBit = 1ull << lane;
@@ -329,9 +360,9 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const LzTab& table, LzStr
     // fast.h:57-58 in block-relative positions: lowLimit is fixed at sub-block entry
     const u32 lowPos = S > LZ_MAX_DIST_LZ4 ? S - LZ_MAX_DIST_LZ4 : 0u;
 
-    if (S >= st.sweepAt) { lz_tab_sweep<HASHLOG>(table, S, false); st.sweepAt = S + 32768u; lz_lds_sync(); }
-    if (lane == 0) { const u64 b0 = lz_ld64(src + S); lz_tab_set(table, lz_hash5<HASHLOG>(b0), lz_tab_entry(S, (u32)b0)); }   // fast.h:66
-    lz_lds_sync();
+    if constexpr (TAB::kSweeps) if (S >= st.sweepAt) { lz_tab_sweep<HASHLOG>(table, S, false); st.sweepAt = S + 32768u; table.sync(); }
+    if (lane == 0) { const u64 b0 = lz_ld64(src + S); table.set(lz_hash5<HASHLOG>(b0), table.entry(S, (u32)b0)); }   // fast.h:66
+    table.sync();
 
     u32 ip = S + 1u;        // uniform: run start, or (special==1) the post-match probe position
     u32 special = 0;        // uniform
@@ -356,22 +387,21 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const LzTab& table, LzStr
                 pNext = pAhead;
                 if (!validNext) pAhead = S;                              // any readable address
             }
-            {   // keep every live slot younger than 2^17 positions (see LzTab)
+            if constexpr (TAB::kSweeps) {   // keep every live slot younger than 2^17 positions (see LzTab)
                 const u32 p0 = lz_readlane(p, 0);
-                if (p0 >= st.sweepAt) { lz_tab_sweep<HASHLOG>(table, p0, false); st.sweepAt = p0 + 32768u; lz_lds_sync(); }
+                if (p0 >= st.sweepAt) { lz_tab_sweep<HASHLOG>(table, p0, false); st.sweepAt = p0 + 32768u; table.sync(); }
             }
             // (slots past mflimit hold stale bytes and a meaningless hash; `valid` keeps them out of every decision
             //  and their stores go to the trash slot — the round itself is branch-free up to the candidate batch)
             const u32 first4 = (u32)bytes;
             const u32 h = lz_hash5<HASHLOG>(bytes);
-            const u32 mine = lz_tab_entry(p, first4);
-            u32 e = lz_tab_get(table, h);                                // fast.h:86 (value before this round)
+            const u32 mine = table.entry(p, first4);
+            u32 e = table.get(h);                                        // fast.h:86 (value before this round)
             lz_converge();                                               // every lane has read before any lane puts
-            lz_tab_set(table, valid ? h : (1u << HASHLOG), mine);        // speculative put (fast.h:88); undone below if needed
-            lz_lds_sync();
+            table.set(valid ? h : (1u << HASHLOG), mine);                // speculative put (fast.h:88); undone below if needed
+            table.sync();
             // two slots of this round on one table slot: the later must see the earlier's put, in order
-            // (positions of one round differ by < 2^16, so the low halves alone tell the writers apart)
-            const bool lost = valid && table.lo[h] != (u16)mine;
+            const bool lost = valid && table.lostPut(h, mine);
             u64 pend = lz_ballot(lost);                                  // uniform
             u64 grp = laneBit;                                           // lanes of this round on my table slot
             const u32 eOld = e;
@@ -390,9 +420,9 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const LzTab& table, LzStr
                 if (prev) e = ej;
             }
             // accept test, fast.h:90-97 (check bits first: they decide whether any bytes are fetched)
-            const u32 age = lz_tab_age(p, e);
+            const u32 age = table.age(p, e);
             const u32 ep = p - age;
-            const bool cand = valid && !putOnly && ((e ^ mine) >> 17) == 0 && age >= LZ_MIN_OFFSET && age <= LZ_MAX_DIST_LZ4
+            const bool cand = valid && !putOnly && table.sameCheck(e, mine) && age >= LZ_MIN_OFFSET && age <= LZ_MAX_DIST_LZ4
                            && age <= p - lowPos;
             u64 cA = 0, cB = 0, pB = 0, cC = 0, pC = 0, cZ = 0, pZ = 0;
             const bool haveBack = cand && ep >= 8u;                      // then p >= 16 as well
@@ -435,9 +465,9 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const LzTab& table, LzStr
                 const bool undo = single ? !(commit & laneBit)           // my own put did not happen
                                          : (c == 0 && (grp & lanesBelow) == 0);   // whole group undone: its first lane restores
                 const bool redo = !single && c != 0 && (c >> lane) == 1ull;       // last committed slot of the group wins
-                lz_tab_set(table, (valid && (undo || redo)) ? h : (1u << HASHLOG), undo ? eOld : mine);
+                table.set((valid && (undo || redo)) ? h : (1u << HASHLOG), undo ? eOld : mine);
             }
-            lz_lds_sync();
+            table.sync();
             LZ_PROF(st, 1);                                              // round part B: candidate wait, ballots, slot settle
             if (okMask) {
                 P = lz_readlane(p, w); M = lz_readlane(ep, w);
@@ -592,7 +622,8 @@ LZ_DEV u32 lz_write_subblock_fast(const u8* src, u32 S, u32 E, u8* op, LzStreams
 // ---- one API block: reference Lizard_compress_extState on a zeroed state (lizard_compress.c:583) ----
 // dst must have room for Lizard_compressBound(n) bytes. Returns the compressed size (uniform).
 // seqRing:  fast parser -> LZ_SEQ_RING u64 of LDS (may be null for priceFast).
-// tableMem: LZ_TAB_BYTES(HASHLOG) bytes (24-bit slots, see LzTab) for both parsers.
+// tableMem: LZ_TAB_BYTES(HASHLOG) bytes (24-bit slots, see LzTab); fast parser with HASHLOG > 14:
+//           LZ_TABWIDE_BYTES(HASHLOG) bytes of 16-byte aligned global memory (LzTabWide, blocks <= 4 MiB).
 // AUX:      priceFast only -> TAGLOG of the round tag array.
 // PARSER: 0 = fastSmall/fast + fastLZ4 codewords, 1 = priceFast + LIZv1 codewords.
 #define LZ_PARSER_FAST      0
@@ -607,8 +638,12 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
     st.prof_last = __builtin_readcyclecounter();
     for (int k = 0; k < 16; k++) st.prof[k] = 0;
 #endif
-    LzTab tab = lz_tab_bind<HASHLOG>(tableMem);
-    if constexpr (PARSER == LZ_PARSER_FAST) { lz_tab_sweep<HASHLOG>(tab, 0, true); st.sweepAt = 32768u; }
+    // fast parser: 24-bit LDS slots up to hashLog 14, wide u32 slots in global memory above; priceFast: 24-bit LDS slots
+    constexpr bool kWide = PARSER == LZ_PARSER_FAST && HASHLOG > 14;
+    LzTab tab = lz_tab_bind<kWide ? 1 : HASHLOG>(tableMem);
+    LzTabWide tabw; tabw.w = (u32*)tableMem;
+    if constexpr (kWide) lz_tab_fresh<HASHLOG>(tabw);
+    else if constexpr (PARSER == LZ_PARSER_FAST) { lz_tab_fresh<HASHLOG>(tab); st.sweepAt = 32768u; }
     else for (u32 i = lane; i < (1u << HASHLOG); i += 64u) lz_tab_set(tab, i, LZ_EMPTY24);
     lz_wave_sync();
     LZ_PROF(st, 6);                                           // table init
@@ -619,7 +654,8 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
         const u32 part = (n - pos) < LZ_SUBBLOCK ? (n - pos) : LZ_SUBBLOCK;
         st.nlit = st.nflags = st.noff16 = st.noff24 = 0;      // Lizard_initBlock, :130-138
         st.nseq = 0; st.lastLits = 0;
-        if constexpr (PARSER == LZ_PARSER_FAST) lz_parse_fast<HASHLOG>(src, pos, pos + part, tab, st);
+        if constexpr (kWide)                         lz_parse_fast<HASHLOG>(src, pos, pos + part, tabw, st);
+        else if constexpr (PARSER == LZ_PARSER_FAST) lz_parse_fast<HASHLOG>(src, pos, pos + part, tab, st);
         else                                    lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, tab, ws, st);
         if constexpr (PARSER == LZ_PARSER_FAST) op += lz_write_subblock_fast<HUF>(src, pos, pos + part, dst + op, st, (u32*)ws);
         else if constexpr (HUF)                 op += lz_write_subblock_huf(src + pos, part, dst + op, st, (u32*)ws);

@@ -17,6 +17,7 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 
 #define LZ_DEV __device__ __forceinline__
+#define LZ_DEVM __device__ __forceinline__       /* member functions */
 #define LZ_DEV_NOINLINE __device__ __noinline__
 #define LZ_WAVE 64
 

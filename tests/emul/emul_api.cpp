@@ -26,11 +26,11 @@ extern "C" int emul_compress_block(const void* src, int n, void* dst, int level,
     int hashLog = base == 10 ? 12 : base == 11 ? 18 : base == 21 ? 14 : base == 22 ? 18 : 0;
     if (!hashLog) return -1;
     a.src = (const u8*)src; a.n = (u32)n; a.dst = (u8*)dst; a.level = (u32)level; a.result = 0;
-    a.table = (u32*)malloc(sizeof(u32) << hashLog);
+    a.table = (u32*)aligned_alloc(64, (sizeof(u32) << hashLog) + 64);
     a.tag = (u8*)malloc(8192);
     a.scratch = (u8*)malloc(LZ_SCRATCH_BYTES);
     u64 ring[LZ_SEQ_RING]; memset(ring, 0xEE, sizeof ring); a.ring = ring;
-    memset(a.table, 0xA5, sizeof(u32) << hashLog);   // garbage: the kernel must initialise its state
+    memset(a.table, 0xA5, (sizeof(u32) << hashLog) + 64);   // garbage: the kernel must initialise its state
     memset(a.tag, 0x5A, 8192);
     memset(a.scratch, 0xCC, LZ_SCRATCH_BYTES);
     static_assert(4 * LZ_HUF_WS_WORDS <= 8192, "emulated LDS workspace too small");

@@ -26,7 +26,9 @@ typedef uint16_t u16;
 typedef uint32_t u32;
 typedef uint64_t u64;
 
+struct uint4 { uint32_t x, y, z, w; };
 #define LZ_DEV static inline
+#define LZ_DEVM inline
 #define LZ_DEV_NOINLINE static __attribute__((noinline))
 #define LZ_WAVE 64
 
