@@ -485,8 +485,14 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
             u32 segBytes[4], tot = hdr + 6u;
             for (u32 k = 0; k < 4u; k++) {
                 const u32 a = k * seg, b = (k == 3u) ? n : (k + 1u) * seg;
-                u32 bits = 0;
-                for (u32 i = a + lane; i < b; i += 64u) bits += (u32)ctab[stream[i]] >> 12;
+                u32 bits = 0;                                  // 4 symbols per lane per step (vector-memory cost is per instruction)
+                const u32 n4 = (b - a) & ~3u;
+                for (u32 i = lane * 4u; i < n4; i += 256u) {
+                    const u32 w = lz_ld32(stream + a + i);
+                    bits += ((u32)ctab[w & 255u] >> 12) + ((u32)ctab[(w >> 8) & 255u] >> 12)
+                          + ((u32)ctab[(w >> 16) & 255u] >> 12) + ((u32)ctab[w >> 24] >> 12);
+                }
+                for (u32 i = a + n4 + lane; i < b; i += 64u) bits += (u32)ctab[stream[i]] >> 12;
                 bits = lz_wave_reduce_add(bits);
                 segBytes[k] = (bits + 1u + 7u) >> 3;
                 tot += segBytes[k];
