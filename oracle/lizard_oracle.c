@@ -29,11 +29,12 @@
 #define LZO_FLAG_LEN          16
 #define LZO_FLAG_UNCOMPRESSED 128
 
-typedef enum { P_FAST, P_PRICEFAST } lzo_parser;
+typedef enum { P_FAST, P_PRICEFAST, P_HASHCHAIN } lzo_parser;
 typedef enum { C_LZ4, C_LIZV1 } lzo_codewords;
 
 typedef struct {
     unsigned windowLog, hashLog, minMatchLongOff;
+    unsigned contentLog, searchNum, searchLength;   /* hashChain only (lizard_common.h:240-244) */
     lzo_parser parser;
     lzo_codewords codewords;
     int huffman;
@@ -44,9 +45,18 @@ static int lzo_get_params(int level, lzo_params* p)
 {
     int base = level >= 30 ? level - 20 : level;
     p->huffman = level >= 30;
+    p->contentLog = 0; p->searchNum = 0; p->searchLength = 5;
+    if (level >= 34 && level <= 38) base = level - 21;          /* 34..38 repeat the rows of 13..17 (lizard_common.h:264-268) */
+    else if (level == 32 || level == 33 || level == 39 || level == 12 || level == 18 || level == 19) return 0;
     switch (base) {
     case 10: p->windowLog = 16; p->hashLog = 12; p->minMatchLongOff = 0;  p->parser = P_FAST;      p->codewords = C_LZ4;   return 1;
     case 11: p->windowLog = 16; p->hashLog = 18; p->minMatchLongOff = 0;  p->parser = P_FAST;      p->codewords = C_LZ4;   return 1;
+    /* hashChain, LZ4 codewords: lizard_common.h:240-244 (13-17) and :264-268 (34-38) */
+    case 13: case 14: case 15: case 16: case 17: {
+        static const unsigned snum[5] = { 2, 4, 8, 16, 256 }, slen[5] = { 5, 5, 5, 4, 4 };
+        p->windowLog = 16; p->hashLog = 18; p->minMatchLongOff = 0; p->contentLog = 16;
+        p->searchNum = snum[base - 13]; p->searchLength = slen[base - 13];
+        p->parser = P_HASHCHAIN; p->codewords = C_LZ4; return 1; }
     case 21: p->windowLog = 22; p->hashLog = 14; p->minMatchLongOff = 16; p->parser = P_PRICEFAST; p->codewords = C_LIZV1; return 1;
     case 22: p->windowLog = 22; p->hashLog = 18; p->minMatchLongOff = 16; p->parser = P_PRICEFAST; p->codewords = C_LIZV1; return 1;
     default: return 0;
@@ -81,6 +91,9 @@ static uint32_t hash5(const uint8_t* p, unsigned hashLog)
     return (uint32_t)(((rd64(p) * 889523592379ULL) << 24) >> (64 - hashLog));
 }
 
+/* reference lib/lizard_compress.c:87-88 (searchLength 4) */
+static uint32_t hash4(const uint8_t* p, unsigned hashLog) { return (rd32(p) * 2654435761U) >> (32 - hashLog); }
+
 /* reference lib/lizard_common.h:475-490: length of the common prefix of src[a..] and src[b..],
  * never letting a reach `limit`. (The 8/4/2/1-byte stepping of the reference is unobservable.) */
 static uint32_t count_eq(const uint8_t* src, uint32_t a, uint32_t b, uint32_t limit)
@@ -98,6 +111,8 @@ typedef struct {
     uint8_t *lit, *flags, *off16, *off24;     /* sub-block stream staging (lizard_compress.c:379-384) */
     uint32_t nlit, nflags, noff16, noff24;    /* the `len` stream is never written by these codewords */
     uint32_t last_off;     /* LIZv1 repeat offset, reset per sub-block (lizard_compress.c:137) */
+    uint32_t* chain;       /* hashChain: 2^contentLog deltas (DELTANEXT, lizard_compress.c:58) */
+    uint32_t nextToUpdate; /* hashChain: first position not yet inserted (block-relative), lizard_compress.c:334 */
 } lzo_ctx;
 
 /* length escape shared by all codewords: reference lib/lizard_compress_lz4.h:21-23 */
@@ -315,6 +330,179 @@ static void parse_pricefast(lzo_ctx* c, uint32_t S, uint32_t E)
     emit_last_literals(c, anchor, E);
 }
 
+/* ---- hashChain parser: reference lib/lizard_parser_hashchain.h ------------------------------------ */
+#define HC_OPTIMAL_ML 18        /* (ML_MASK_LZ4-1)+MINMATCH, hashchain.h:3 */
+
+static uint32_t hc_hash(const lzo_ctx* c, uint32_t pos)
+{
+    return c->prm.searchLength == 4 ? hash4(c->src + pos, c->prm.hashLog) : hash5(c->src + pos, c->prm.hashLog);
+}
+
+/* Lizard_Insert, hashchain.h:13-43: chain + conditional head update for every position below `target`. */
+static void hc_insert(lzo_ctx* c, uint32_t target)
+{
+    const uint32_t mask = (1u << c->prm.contentLog) - 1, maxDist = (1u << c->prm.windowLog) - 1;
+    uint32_t pos = c->nextToUpdate;
+    while (pos < target) {
+        const uint32_t idx = pos + LZO_DICT_SIZE, h = hc_hash(c, pos), head = c->table[h];
+        uint32_t delta = idx - head;
+        if (delta > maxDist) delta = maxDist;
+        c->chain[idx & mask] = delta;
+        if (head >= idx || idx >= head + LZO_MIN_OFFSET) c->table[h] = idx;
+        pos++;
+    }
+    c->nextToUpdate = target;
+}
+
+/* Lizard_InsertAndFindBestMatch, hashchain.h:45-107. Returns length (0 = none), *ref = match position. */
+static int hc_find_best(lzo_ctx* c, uint32_t ip, uint32_t iLimit, uint32_t* ref)
+{
+    const uint8_t* src = c->src;
+    const uint32_t mask = (1u << c->prm.contentLog) - 1, maxDist = (1u << c->prm.windowLog) - 1;
+    const uint32_t cur = ip + LZO_DICT_SIZE;
+    const uint32_t lowLimit = (LZO_DICT_SIZE + maxDist >= cur) ? LZO_DICT_SIZE : cur - maxDist;
+    int attempts = (int)c->prm.searchNum;
+    uint32_t ml = 0, mi;
+    hc_insert(c, ip);
+    mi = c->table[hc_hash(c, ip)];
+    while (mi < cur && mi >= lowLimit && attempts) {
+        const uint32_t m = mi - LZO_DICT_SIZE;
+        uint32_t delta;
+        attempts--;
+        if (ip - m >= LZO_MIN_OFFSET && src[m + ml] == src[ip + ml] && rd32(src + m) == rd32(src + ip)) {
+            const uint32_t mlt = LZO_MINMATCH + count_eq(src, ip + 4, m + 4, iLimit);
+            if (mlt > ml) { ml = mlt; *ref = m; }
+        }
+        delta = c->chain[mi & mask];
+        if (delta > mi) break;
+        mi -= delta;
+    }
+    return (int)ml;
+}
+
+/* Lizard_InsertAndGetWiderMatch, hashchain.h:109-185. */
+static int hc_wider(lzo_ctx* c, uint32_t ip, uint32_t iLow, uint32_t iHigh, int longest, uint32_t* ref, uint32_t* start)
+{
+    const uint8_t* src = c->src;
+    const uint32_t mask = (1u << c->prm.contentLog) - 1, maxDist = (1u << c->prm.windowLog) - 1;
+    const uint32_t cur = ip + LZO_DICT_SIZE;
+    const uint32_t lowLimit = (LZO_DICT_SIZE + maxDist >= cur) ? LZO_DICT_SIZE : cur - maxDist;
+    const int LLdelta = (int)(ip - iLow);
+    int attempts = (int)c->prm.searchNum;
+    uint32_t mi;
+    hc_insert(c, ip);
+    mi = c->table[hc_hash(c, ip)];
+    while (mi < cur && mi >= lowLimit && attempts) {
+        const uint32_t m = mi - LZO_DICT_SIZE;
+        uint32_t delta;
+        attempts--;
+        if (ip - m >= LZO_MIN_OFFSET && src[iLow + longest] == src[m - LLdelta + longest] && rd32(src + m) == rd32(src + ip)) {
+            int mlt = LZO_MINMATCH + (int)count_eq(src, ip + 4, m + 4, iHigh), back = 0;
+            while (ip + back > iLow && m + back > 0 && src[ip + back - 1] == src[m + back - 1]) back--;
+            mlt -= back;
+            if (mlt > longest) { longest = mlt; *ref = m + back; *start = ip + back; }
+        }
+        delta = c->chain[mi & mask];
+        if (delta > mi) break;
+        mi -= delta;
+    }
+    return longest;
+}
+
+/* Lizard_compress_hashChain, hashchain.h:188-369 (LZ4HC-style three-match lazy arbitration). */
+static void parse_hashchain(lzo_ctx* c, uint32_t S, uint32_t E)
+{
+    int anchor = (int)S, ip = (int)S, mflimit, matchlimit;
+    int ml, ml2, ml3, ml0;
+    uint32_t ref = 0, ref2 = 0, ref3 = 0, ref0, start2 = 0, start3 = 0;
+    int start0;
+    /* mflimit is a pointer difference in the reference; a sub-block shorter than MFLIMIT never enters the loop */
+    mflimit = (int)E - (int)LZO_MFLIMIT; matchlimit = (int)E - (int)LZO_LASTLITERALS;
+    ip++;
+    while (ip < mflimit) {
+        ml = hc_find_best(c, (uint32_t)ip, (uint32_t)matchlimit, &ref);
+        if (!ml) { ip++; continue; }
+        start0 = ip; ref0 = ref; ml0 = ml;
+    search2:
+        if (ip + ml < mflimit) ml2 = hc_wider(c, (uint32_t)(ip + ml - 2), (uint32_t)(ip + 1), (uint32_t)matchlimit, ml, &ref2, &start2);
+        else ml2 = ml;
+        if (ml2 == ml) {                                                          /* :216-219 */
+            emit_seq(c, (uint32_t)anchor, (uint32_t)ip, (uint32_t)ml, ref); ip += ml; anchor = ip;
+            continue;
+        }
+        if (start0 < ip) {                                                        /* :221-227 */
+            if ((int)start2 < ip + ml0) { ip = start0; ref = ref0; ml = ml0; }
+        }
+        if ((int)start2 - ip < 3) {                                               /* :230-235 */
+            ml = ml2; ip = (int)start2; ref = ref2;
+            goto search2;
+        }
+    search3:
+        if ((int)start2 - ip < HC_OPTIMAL_ML) {                                   /* :243-260 */
+            int correction, new_ml = ml;
+            if (new_ml > HC_OPTIMAL_ML) new_ml = HC_OPTIMAL_ML;
+            if (ip + new_ml > (int)start2 + ml2 - LZO_MINMATCH) {
+                new_ml = (int)start2 - ip + ml2 - LZO_MINMATCH;
+                if (new_ml < LZO_MINMATCH) {
+                    emit_seq(c, (uint32_t)anchor, (uint32_t)ip, (uint32_t)ml, ref); ip += ml; anchor = ip;
+                    continue;
+                }
+            }
+            correction = new_ml - ((int)start2 - ip);
+            if (correction > 0) { start2 += (uint32_t)correction; ref2 += (uint32_t)correction; ml2 -= correction; }
+        }
+        if ((int)start2 + ml2 < mflimit)                                          /* :263-265 */
+            ml3 = hc_wider(c, start2 + (uint32_t)ml2 - 3, start2, (uint32_t)matchlimit, ml2, &ref3, &start3);
+        else ml3 = ml2;
+        if (ml3 == ml2) {                                                         /* :267-275 */
+            if ((int)start2 < ip + ml) ml = (int)start2 - ip;
+            emit_seq(c, (uint32_t)anchor, (uint32_t)ip, (uint32_t)ml, ref); ip += ml; anchor = ip;
+            ip = (int)start2;
+            emit_seq(c, (uint32_t)anchor, (uint32_t)ip, (uint32_t)ml2, ref2); ip += ml2; anchor = ip;
+            continue;
+        }
+        if ((int)start3 < ip + ml + 3) {                                          /* :277-305 */
+            if ((int)start3 >= ip + ml) {
+                if ((int)start2 < ip + ml) {
+                    int correction = ip + ml - (int)start2;
+                    start2 += (uint32_t)correction; ref2 += (uint32_t)correction; ml2 -= correction;
+                    if (ml2 < LZO_MINMATCH) { start2 = start3; ref2 = ref3; ml2 = ml3; }
+                }
+                emit_seq(c, (uint32_t)anchor, (uint32_t)ip, (uint32_t)ml, ref); ip += ml; anchor = ip;
+                ip = (int)start3; ref = ref3; ml = ml3;
+                start0 = (int)start2; ref0 = ref2; ml0 = ml2;
+                goto search2;
+            }
+            start2 = start3; ref2 = ref3; ml2 = ml3;
+            goto search3;
+        }
+        if ((int)start2 < ip + ml) {                                              /* :311-338 */
+            if ((int)start2 - ip < 15) {
+                int correction;
+                if (ml > HC_OPTIMAL_ML) ml = HC_OPTIMAL_ML;
+                if (ip + ml > (int)start2 + ml2 - LZO_MINMATCH) {
+                    ml = (int)start2 - ip + ml2 - LZO_MINMATCH;
+                    if (ml < LZO_MINMATCH) {
+                        emit_seq(c, (uint32_t)anchor, (uint32_t)ip, (uint32_t)ml, ref); ip += ml; anchor = ip;
+                        ip = (int)start3; ref = ref3; ml = ml3;
+                        start0 = (int)start2; ref0 = ref2; ml0 = ml2;
+                        goto search2;
+                    }
+                }
+                correction = ml - ((int)start2 - ip);
+                if (correction > 0) { start2 += (uint32_t)correction; ref2 += (uint32_t)correction; ml2 -= correction; }
+            } else {
+                ml = (int)start2 - ip;
+            }
+        }
+        emit_seq(c, (uint32_t)anchor, (uint32_t)ip, (uint32_t)ml, ref); ip += ml; anchor = ip;   /* :339 */
+        ip = (int)start2; ref = ref2; ml = ml2;
+        start2 = start3; ref2 = ref3; ml2 = ml3;
+        goto search3;
+    }
+    emit_last_literals(c, (uint32_t)anchor, E);
+}
+
 /* ---- sub-block container: reference lib/lizard_compress.c:141-250 ------------------------------- */
 
 #define LZO_HUF_GAIN(c)   ((c) + ((c) / 8) + 512)     /* lizard_compress.c:59 */
@@ -397,10 +585,12 @@ int lzo_compress(const void* srcv, void* dstv, int srcSize, int dstCapacity, int
 
     c.src = src;
     c.table = (uint32_t*)calloc((size_t)1 << c.prm.hashLog, sizeof(uint32_t));
+    c.chain = (uint32_t*)calloc((size_t)1 << 16, sizeof(uint32_t));
+    c.nextToUpdate = 0;
     c.lit   = (uint8_t*)malloc(4 * (size_t)LZO_SUBBLOCK_PAD);
     hufTmpCap = LZO_SUBBLOCK_PAD + (LZO_SUBBLOCK_PAD >> 8) + 8 + 129 + 64;      /* >= HUF_compressBound */
     hufTmp  = (uint8_t*)malloc(hufTmpCap);
-    if (!c.table || !c.lit || !hufTmp) goto done;
+    if (!c.table || !c.chain || !c.lit || !hufTmp) goto done;
     c.flags = c.lit + LZO_SUBBLOCK_PAD;
     c.off16 = c.flags + LZO_SUBBLOCK_PAD;
     c.off24 = c.off16 + LZO_SUBBLOCK_PAD;
@@ -412,13 +602,14 @@ int lzo_compress(const void* srcv, void* dstv, int srcSize, int dstCapacity, int
         if (part > LZO_SUBBLOCK) part = LZO_SUBBLOCK;
         c.nlit = c.nflags = c.noff16 = c.noff24 = 0; c.last_off = 0;              /* Lizard_initBlock :130-138 */
         if (c.prm.parser == P_FAST) parse_fast(&c, pos, pos + part);
+        else if (c.prm.parser == P_HASHCHAIN) parse_hashchain(&c, pos, pos + part);
         else parse_pricefast(&c, pos, pos + part);
         if (write_block(&c, src + pos, part, &op, oend, hufTmp, hufTmpCap)) goto done;   /* :535 */
         pos += part;
     }
     result = (int)(op - dst);
 done:
-    free(c.table); free(c.lit); free(hufTmp);
+    free(c.table); free(c.chain); free(c.lit); free(hufTmp);
     return result;
 }
 

@@ -15,7 +15,7 @@ import xxhash
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import util  # noqa: E402
 
-LEVELS = [10, 11, 21, 22, 30, 31, 41, 42]
+LEVELS = [10, 11, 13, 14, 15, 16, 17, 21, 22, 30, 31, 34, 35, 36, 37, 38, 41, 42]
 
 
 def main():
@@ -43,7 +43,7 @@ def main():
     dg.RDG_genBuffer(buf, N, 0.5, 0.0, 0)
     vec["p50_64m"]["input_sha256"] = util.sha(buf.raw)
     base = ctypes.addressof(buf)
-    for lvl, bs in [(10, 262144), (11, 262144), (21, 262144), (30, 262144), (10, 4 << 20), (10, 65536)]:
+    for lvl, bs in [(10, 262144), (11, 262144), (21, 262144), (30, 262144), (10, 4 << 20), (10, 65536), (13, 262144), (15, 262144), (17, 262144), (35, 262144)]:
         bound = ref.Lizard_compressBound(bs)
         out = ctypes.create_string_buffer(bound)
         tot, h, sizes = 0, 0, []
