@@ -21,7 +21,9 @@ struct LzBatch {
     const u8* src;  u64 blockSize;  u32 nBlocks;  u32 lastBlockSize;
     u8* dst;        u64 dstStride;  u32* sizes;   u32 level;
     u8* scratch;    u32* counter;
-    u8* tables;     // levels 11/31: one LZ_TABWIDE_BYTES(18) hash table per resident wave (global memory)
+    u8* tables;     // levels 11/31: one LZ_TABWIDE_BYTES(18) hash table per resident wave (global memory);
+                    // hashChain levels: one LZ_HC_SLOT_BYTES(maxBlock) slot per resident wave
+    u64 tableStride;
 };
 
 // Residency by construction.  LDS is what limits the number of blocks in flight, and the hardware hands it
@@ -41,14 +43,14 @@ struct LzBatch {
 template <int PARSER, int HASHLOG, int AUX, bool HUF, int W, int WSWORDS>
 __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
 {
-    constexpr bool kGlobalTable = HASHLOG > 14;                      // hashLog 18 (levels 11/31): 1 MiB per wave, not LDS
-    struct Slice { u32 table[kGlobalTable ? 1 : LZ_TAB_BYTES(HASHLOG) / 4u]; u64 ring[PARSER == LZ_PARSER_FAST ? LZ_SEQ_RING : 1]; u32 ws[WSWORDS]; };
+    constexpr bool kGlobalTable = HASHLOG > 14;                      // hashLog 18 (levels 11/31, hashChain): 1 MiB per wave, not LDS
+    struct Slice { u32 table[kGlobalTable ? 1 : LZ_TAB_BYTES(HASHLOG) / 4u]; u64 ring[PARSER != LZ_PARSER_PRICEFAST ? LZ_SEQ_RING : 1]; u32 ws[WSWORDS]; };
     __shared__ Slice lds[W];
     const u32 wave = threadIdx.x >> 6;
     Slice& my = lds[wave];
     const u64 slot = (u64)blockIdx.x * W + wave;
     u8* scratch = a.scratch + slot * LZ_SCRATCH_BYTES;
-    void* tableMem = kGlobalTable ? (void*)(a.tables + slot * LZ_TABWIDE_BYTES(18)) : (void*)my.table;
+    void* tableMem = kGlobalTable ? (void*)(a.tables + slot * a.tableStride) : (void*)my.table;
     for (;;) {
         lz_converge();
         const u32 b = lz_claim_index(a.counter);
@@ -76,6 +78,15 @@ __global__ __launch_bounds__(64 * LZ_WAVES_FAST18) void lz_fast18_kernel(LzBatch
     lz_wave_main<LZ_PARSER_FAST, 18, 0, HUF, LZ_WAVES_FAST18, (HUF ? LZ_HUF_WS_WORDS : 1)>(a);
 }
 
+// levels 13-17 / 34-38: hashChain parser (searchLength 5 for rows 13-15, 4 for 16-17; searchNum comes from the
+// level at run time).  Per wave: head table + chain array in global memory, 2 KiB tag array / Huffman workspace in LDS.
+#define LZ_WAVES_HC 16
+template <bool HUF, int SEARCHLEN>
+__global__ __launch_bounds__(64 * LZ_WAVES_HC) void lz_hashchain_kernel(LzBatch a)
+{
+    lz_wave_main<LZ_PARSER_HASHCHAIN, 18, SEARCHLEN, HUF, LZ_WAVES_HC, (HUF ? LZ_HUF_WS_WORDS : (1u << LZ_HC_TAGLOG) / 4u)>(a);
+}
+
 // levels 21 / 41: priceFast + LIZv1, 2^14-slot table (24-bit slots, 48 KiB) + round tag array / Huffman workspace
 template <bool HUF>
 __global__ __launch_bounds__(64 * LZ_WAVES_PF) void lz_pricefast14_kernel(LzBatch a)
@@ -99,6 +110,8 @@ struct Ctx {
     int   wavesHuf = 0;         // persistent grid size (level 30: larger LDS workspace)
     int   wavesPf = 0, wavesPfHuf = 0;   // levels 21 / 41
     u8*   tables = nullptr;     // levels 11 / 31, allocated on first use
+    u8*   hcSlots = nullptr;    // hashChain levels, allocated (and zeroed) on first use / when a larger block size arrives
+    size_t hcMaxBlock = 0;
     u8*   scratch = nullptr;
     u32*  counter = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -172,7 +185,24 @@ int launch_locked(const void* d_src, size_t nBlocks, size_t blockSize, size_t la
     if (lv < LIZARD_MIN_CLEVEL) lv = LIZARD_DEFAULT_CLEVEL;
     a.level = (u32)lv;
     // one workgroup of W waves per CU; small batches launch only as many workgroups as they have blocks for
-    const u32 W = lv == 10 ? LZ_WAVES_FAST : lv == 30 ? LZ_WAVES_FAST_HUF : (lv == 11 || lv == 31) ? LZ_WAVES_FAST18 : LZ_WAVES_PF;
+    const bool hcLevel = (lv >= 13 && lv <= 17) || (lv >= 34 && lv <= 38);
+    const u32 W = lv == 10 ? LZ_WAVES_FAST : lv == 30 ? LZ_WAVES_FAST_HUF : (lv == 11 || lv == 31) ? LZ_WAVES_FAST18 : hcLevel ? LZ_WAVES_HC : LZ_WAVES_PF;
+    a.tableStride = LZ_TABWIDE_BYTES(18);
+    if (hcLevel) {
+        if (blockSize > (4u << 20)) {
+            snprintf(g_ctx.err, sizeof g_ctx.err, "hashChain levels: blocks above 4 MiB are not supported on the GPU path");
+            return -LIZARDGPU_ERR_ARG;
+        }
+        const size_t cap = (blockSize + 65535u) & ~(size_t)65535u;
+        if (!g_ctx.hcSlots || g_ctx.hcMaxBlock < cap) {
+            if (g_ctx.hcSlots) { LZ_HIP(hipDeviceSynchronize()); LZ_HIP(hipFree(g_ctx.hcSlots)); g_ctx.hcSlots = nullptr; g_ctx.hcMaxBlock = 0; }
+            const size_t bytes = (size_t)g_ctx.cus * LZ_WAVES_HC * LZ_HC_SLOT_BYTES(cap);
+            LZ_HIP(hipMalloc((void**)&g_ctx.hcSlots, bytes));
+            LZ_HIP(hipMemset(g_ctx.hcSlots, 0, bytes));              // epoch 0 = never used (lz_hc_begin)
+            g_ctx.hcMaxBlock = cap;
+        }
+        a.tables = g_ctx.hcSlots; a.tableStride = LZ_HC_SLOT_BYTES(g_ctx.hcMaxBlock);
+    }
     if (lv == 11 || lv == 31) {
         if (blockSize > (4u << 20)) {
             snprintf(g_ctx.err, sizeof g_ctx.err, "levels 11/31: blocks above 4 MiB are not supported on the GPU path");
@@ -192,6 +222,10 @@ int launch_locked(const void* d_src, size_t nBlocks, size_t blockSize, size_t la
     case 30: hipLaunchKernelGGL(lz_fast12_kernel<true>, dim3(grid), dim3(64 * LZ_WAVES_FAST_HUF), 0, stream, a); break;
     case 11: hipLaunchKernelGGL(lz_fast18_kernel<false>, dim3(grid), dim3(64 * LZ_WAVES_FAST18), 0, stream, a); break;
     case 31: hipLaunchKernelGGL(lz_fast18_kernel<true>, dim3(grid), dim3(64 * LZ_WAVES_FAST18), 0, stream, a); break;
+    case 13: case 14: case 15: hipLaunchKernelGGL((lz_hashchain_kernel<false, 5>), dim3(grid), dim3(64 * LZ_WAVES_HC), 0, stream, a); break;
+    case 16: case 17:          hipLaunchKernelGGL((lz_hashchain_kernel<false, 4>), dim3(grid), dim3(64 * LZ_WAVES_HC), 0, stream, a); break;
+    case 34: case 35: case 36: hipLaunchKernelGGL((lz_hashchain_kernel<true, 5>), dim3(grid), dim3(64 * LZ_WAVES_HC), 0, stream, a); break;
+    case 37: case 38:          hipLaunchKernelGGL((lz_hashchain_kernel<true, 4>), dim3(grid), dim3(64 * LZ_WAVES_HC), 0, stream, a); break;
     case 21: hipLaunchKernelGGL(lz_pricefast14_kernel<false>, dim3(grid), dim3(64 * LZ_WAVES_PF), 0, stream, a); break;
     default: hipLaunchKernelGGL(lz_pricefast14_kernel<true>, dim3(grid), dim3(64 * LZ_WAVES_PF), 0, stream, a); break;
     }
@@ -219,7 +253,8 @@ int LizardGPU_levelSupported(int level)
 {
     if (level > LIZARD_MAX_CLEVEL) level = LIZARD_MAX_CLEVEL;        // reference lizard_compress.c:303-308
     if (level < LIZARD_MIN_CLEVEL) level = LIZARD_DEFAULT_CLEVEL;
-    return level == 10 || level == 30 || level == 11 || level == 31 || level == 21 || level == 41;
+    return level == 10 || level == 30 || level == 11 || level == 31 || level == 21 || level == 41
+        || (level >= 13 && level <= 17) || (level >= 34 && level <= 38);
 }
 
 int LizardGPU_setDevice(int device)

@@ -500,6 +500,7 @@ tail:
 LZ_DEV void lz_st24(u8* p, u32 v) { p[0] = (u8)v; p[1] = (u8)(v >> 8); p[2] = (u8)(v >> 16); }
 
 #include "lz_pricefast.h"   // priceFast parser + LIZv1 encoder (uses the helpers above)
+#include "lz_hashchain.h"   // hashChain parser (fastLZ4 codewords through the sequence list)
 
 // ---- sub-block container (reference lib/lizard_compress.c:141-250) -------------------------------
 
@@ -625,15 +626,19 @@ LZ_DEV u32 lz_write_subblock_fast(const u8* src, u32 S, u32 E, u8* op, LzStreams
 // tableMem: LZ_TAB_BYTES(HASHLOG) bytes (24-bit slots, see LzTab); fast parser with HASHLOG > 14:
 //           LZ_TABWIDE_BYTES(HASHLOG) bytes of 16-byte aligned global memory (LzTabWide, blocks <= 4 MiB).
 // AUX:      priceFast only -> TAGLOG of the round tag array.
-// PARSER: 0 = fastSmall/fast + fastLZ4 codewords, 1 = priceFast + LIZv1 codewords.
+//           hashChain -> searchLength (4 or 5); tableMem = the wave's LZ_HC_SLOT_BYTES slot (global, zeroed once by
+//           the host), ws doubles as the 2^LZ_HC_TAGLOG-byte tag array.
+// PARSER: 0 = fastSmall/fast + fastLZ4 codewords, 1 = priceFast + LIZv1 codewords, 2 = hashChain + fastLZ4 codewords.
 #define LZ_PARSER_FAST      0
 #define LZ_PARSER_PRICEFAST 1
+#define LZ_PARSER_HASHCHAIN 2
 template <int PARSER, int HASHLOG, int AUX, bool HUF>
 LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tableMem, u8* ws, u8* scratch, u64* seqRing)
 {
     const u32 lane = lz_lane();
     LzStreams st;
-    lz_streams_bind(st, scratch, PARSER == LZ_PARSER_FAST, seqRing);
+    constexpr bool kSeqList = PARSER == LZ_PARSER_FAST || PARSER == LZ_PARSER_HASHCHAIN;   // fastLZ4 codewords
+    lz_streams_bind(st, scratch, kSeqList, seqRing);
 #ifdef LZ_PROFILE
     st.prof_last = __builtin_readcyclecounter();
     for (int k = 0; k < 16; k++) st.prof[k] = 0;
@@ -642,7 +647,13 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
     constexpr bool kWide = PARSER == LZ_PARSER_FAST && HASHLOG > 14;
     LzTab tab = lz_tab_bind<kWide ? 1 : HASHLOG>(tableMem);
     LzTabWide tabw; tabw.w = (u32*)tableMem;
-    if constexpr (kWide) lz_tab_fresh<HASHLOG>(tabw);
+    LzHc hc;
+    if constexpr (PARSER == LZ_PARSER_HASHCHAIN) {
+        const u32 row = (level >= 30u ? level - 21u : level) - 13u;                  // lizard_common.h:240-244, :264-268
+        lz_hc_begin(hc, tableMem, ws, row == 4u ? 256u : 2u << row);
+        lz_hc_build<AUX>(src, n, hc);
+    }
+    else if constexpr (kWide) lz_tab_fresh<HASHLOG>(tabw);
     else if constexpr (PARSER == LZ_PARSER_FAST) { lz_tab_fresh<HASHLOG>(tab); st.sweepAt = 32768u; }
     else for (u32 i = lane; i < (1u << HASHLOG); i += 64u) lz_tab_set(tab, i, LZ_EMPTY24);
     lz_wave_sync();
@@ -654,10 +665,11 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
         const u32 part = (n - pos) < LZ_SUBBLOCK ? (n - pos) : LZ_SUBBLOCK;
         st.nlit = st.nflags = st.noff16 = st.noff24 = 0;      // Lizard_initBlock, :130-138
         st.nseq = 0; st.lastLits = 0;
-        if constexpr (kWide)                         lz_parse_fast<HASHLOG>(src, pos, pos + part, tabw, st);
+        if constexpr (PARSER == LZ_PARSER_HASHCHAIN) lz_parse_hashchain(src, pos, pos + part, hc, st);
+        else if constexpr (kWide)                    lz_parse_fast<HASHLOG>(src, pos, pos + part, tabw, st);
         else if constexpr (PARSER == LZ_PARSER_FAST) lz_parse_fast<HASHLOG>(src, pos, pos + part, tab, st);
         else                                    lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, tab, ws, st);
-        if constexpr (PARSER == LZ_PARSER_FAST) op += lz_write_subblock_fast<HUF>(src, pos, pos + part, dst + op, st, (u32*)ws);
+        if constexpr (kSeqList)                 op += lz_write_subblock_fast<HUF>(src, pos, pos + part, dst + op, st, (u32*)ws);
         else if constexpr (HUF)                 op += lz_write_subblock_huf(src + pos, part, dst + op, st, (u32*)ws);
         else                                    op += lz_write_subblock_raw_streams(src + pos, part, dst + op, st);
         LZ_PROF(st, 5);                                       // container: encode pass / stream copies / Huffman

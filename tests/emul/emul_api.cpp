@@ -17,14 +17,29 @@ void entry_block(void* a)
 
 
 
+// hashChain levels keep one persistent, zero-initialised global slot (as the host library does), so the
+// epoch logic of lz_hc_begin is exercised across calls; emul_hc_set_epoch lets a test jump to the wrap.
+static u8* g_hcSlot = nullptr;
+static const size_t kHcMaxBlock = 4u << 20;
+static u8* hc_slot()
+{
+    if (!g_hcSlot) g_hcSlot = (u8*)calloc(1, LZ_HC_SLOT_BYTES(kHcMaxBlock));
+    return g_hcSlot;
+}
+extern "C" void emul_hc_set_epoch(unsigned e) { ((u32*)hc_slot())[1u << LZ_HC_HASHLOG] = e; }
+extern "C" unsigned emul_hc_get_epoch(void) { return ((u32*)hc_slot())[1u << LZ_HC_HASHLOG]; }
+
 // Compress one block with the emulated wave. dst must hold Lizard_compressBound(n) bytes.
 // `seed` drives the lane scheduling order (any value must give identical output).
 extern "C" int emul_compress_block(const void* src, int n, void* dst, int level, unsigned seed)
 {
     Args a;
     int base = level >= 30 ? level - 20 : level;
-    int hashLog = base == 10 ? 12 : base == 11 ? 18 : base == 21 ? 14 : base == 22 ? 18 : 0;
+    if (level >= 34 && level <= 38) base = level - 21;
+    const bool hcLevel = base >= 13 && base <= 17;
+    int hashLog = base == 10 ? 12 : base == 11 ? 18 : base == 21 ? 14 : base == 22 ? 18 : hcLevel ? 18 : 0;
     if (!hashLog) return -1;
+    if (hcLevel && (size_t)n > kHcMaxBlock) return -1;
     a.src = (const u8*)src; a.n = (u32)n; a.dst = (u8*)dst; a.level = (u32)level; a.result = 0;
     a.table = (u32*)aligned_alloc(64, (sizeof(u32) << hashLog) + 64);
     a.tag = (u8*)malloc(8192);
@@ -35,13 +50,17 @@ extern "C" int emul_compress_block(const void* src, int n, void* dst, int level,
     memset(a.scratch, 0xCC, LZ_SCRATCH_BYTES);
     static_assert(4 * LZ_HUF_WS_WORDS <= 8192, "emulated LDS workspace too small");
     const bool huf = level >= 30;
+    void* garbageTable = a.table;
+    if (hcLevel) a.table = (u32*)hc_slot();
     switch (base) {
+    case 13: case 14: case 15: lzemu::run_wave(huf ? entry_block<LZ_PARSER_HASHCHAIN, 18, 5, true> : entry_block<LZ_PARSER_HASHCHAIN, 18, 5, false>, &a, seed); break;
+    case 16: case 17:          lzemu::run_wave(huf ? entry_block<LZ_PARSER_HASHCHAIN, 18, 4, true> : entry_block<LZ_PARSER_HASHCHAIN, 18, 4, false>, &a, seed); break;
     case 10: lzemu::run_wave(huf ? entry_block<LZ_PARSER_FAST, 12, 0, true> : entry_block<LZ_PARSER_FAST, 12, 0, false>, &a, seed); break;
     case 11: lzemu::run_wave(huf ? entry_block<LZ_PARSER_FAST, 18, 0, true> : entry_block<LZ_PARSER_FAST, 18, 0, false>, &a, seed); break;
     case 21: lzemu::run_wave(huf ? entry_block<LZ_PARSER_PRICEFAST, 14, 12, true> : entry_block<LZ_PARSER_PRICEFAST, 14, 12, false>, &a, seed); break;
     default: lzemu::run_wave(huf ? entry_block<LZ_PARSER_PRICEFAST, 18, 12, true> : entry_block<LZ_PARSER_PRICEFAST, 18, 12, false>, &a, seed); break;
     }
-    free(a.table); free(a.tag); free(a.scratch);
+    free(garbageTable); free(a.tag); free(a.scratch);
     return (int)a.result;
 }
 
