@@ -138,10 +138,16 @@ LZ_DEV void lz_hc_build(const u8* src, u32 n, const LzHc& hc)
 // One search of the chain that starts at X (uniform).  wider == false: Lizard_InsertAndFindBestMatch
 // (longest = 0 on entry, iLow unused); wider == true: Lizard_InsertAndGetWiderMatch with backward
 // extension down to iLow.  Returns the new longest; ref/start change only when it grew.
+//
+// Up to 64 chain candidates are measured at once, one per lane: 4-byte test, then 24 more bytes forward
+// and 8 bytes backward with lane-local loads.  Lanes whose comparison is still open after that (long
+// matches) are finished one at a time with the wave-wide helpers, skipping those that cannot reach the
+// best length any more.  "First strictly longer candidate in chain order" == maximum length, lowest lane.
 LZ_DEV u32 lz_hc_search(const u8* src, const LzHc& hc, u32 X, u32 iLow, u32 iHigh, u32 longest, bool wider, u32& ref, u32& start)
 {
     const u32 lane = lz_lane();
     const u32 first4 = lz_ld32(src + X);
+    const u32 maxFwd = iHigh - X;                                // X + 4 < iHigh for every caller
     u32 m = X, left = hc.searchNum;                              // uniform
     bool more = true;
     while (more && left) {
@@ -157,15 +163,57 @@ LZ_DEV u32 lz_hc_search(const u8* src, const LzHc& hc, u32 X, u32 iLow, u32 iHig
         }
         left -= cnt;
         const bool ok = lane < cnt && X - cand >= LZ_MIN_OFFSET && lz_ld32(src + cand) == first4;   // :73 / :146
-        u64 okm = lz_ballot(ok);
-        while (okm) {
-            const u32 j = lz_ctz64(okm);
-            okm &= okm - 1ull;
+        u32 mlt = 0, bk = 0;
+        bool open = false;                                       // my comparison needs the wave-wide helpers
+        if (ok) {
+            u32 f = 4u;
+            bool eq = true;
+            #pragma unroll
+            for (u32 it = 0; it < 3u; it++) {
+                if (eq && f < maxFwd) {
+                    const u64 x = lz_ld64(src + X + f) ^ lz_ld64(src + cand + f);
+                    u32 c8 = x ? lz_ctz64(x) >> 3 : 8u;
+                    const u32 room = maxFwd - f;
+                    c8 = c8 < room ? c8 : room;
+                    f += c8; eq = c8 == 8u;
+                } else eq = false;
+            }
+            open = eq;
+            if (wider) {
+                const u32 lim = (X - iLow) < cand ? (X - iLow) : cand;        // :150 both bounds
+                if (lim) {
+                    if (cand >= 8u) {                                          // X > cand >= 8
+                        const u64 x = lz_ld64(src + X - 8u) ^ lz_ld64(src + cand - 8u);
+                        const u32 e8 = x ? lz_clz64(x) >> 3 : 8u;
+                        bk = e8 < lim ? e8 : lim;
+                        open = open || (e8 == 8u && lim > 8u);
+                    } else open = true;
+                }
+            }
+            mlt = f + bk;
+        }
+        // best of the lanes that are already exact: max length, lowest lane on ties
+        const u32 key = (ok && !open) ? (mlt << 6) | (63u - lane) : 0u;
+        const u32 top = lz_readlane(lz_wave_reduce_max(key), 63u);
+        u32 bestMl = top >> 6, bestLane = 63u - (top & 63u), bestBack = 0;
+        bool bestOpen = false;
+        u64 om = lz_ballot(open);
+        while (om) {
+            const u32 j = lz_ctz64(om);
+            om &= om - 1ull;
             const u32 c = lz_readlane(cand, j);
-            u32 mlt = 4u + lz_count_fwd(src, X + 4u, c + 4u, iHigh);
-            u32 back = 0;
-            if (wider) { back = lz_count_back(src, X, c, iLow); mlt += back; }                      // :150-152
-            if (mlt > longest) { longest = mlt; ref = c - back; start = X - back; }
+            const u32 cap = maxFwd + (wider ? ((X - iLow) < c ? (X - iLow) : c) : 0u);
+            const u32 need = bestMl > longest ? bestMl : longest + 1u;         // what j must reach to matter
+            if (cap < need || (cap == bestMl && bestMl > 0u && j > bestLane)) continue;
+            u32 mj = 4u + lz_count_fwd(src, X + 4u, c + 4u, iHigh);
+            u32 bj = 0;
+            if (wider) { bj = lz_count_back(src, X, c, iLow); mj += bj; }      // :150-152
+            if (mj > bestMl || (mj == bestMl && j < bestLane)) { bestMl = mj; bestLane = j; bestBack = bj; bestOpen = true; }
+        }
+        if (bestMl > longest) {
+            const u32 c = lz_readlane(cand, bestLane);
+            const u32 back = bestOpen ? bestBack : lz_readlane(bk, bestLane);
+            longest = bestMl; ref = c - back; start = X - back;
         }
     }
     return longest;
@@ -201,12 +249,15 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 S, u32 E, const LzHc& hc, LzSt
             if (okMask) { ip += (int)lz_ctz64(okMask); break; }
             ip += (int)lz_popc64(lz_ballot(valid));
         }
+        LZ_PROF(st, 0);
         ml = (int)lz_hc_search(src, hc, (u32)ip, (u32)ip, (u32)matchlimit, 0u, false, ref, dummy);
+        LZ_PROF(st, 1);
         start0 = ip; ref0 = ref; ml0 = ml;                                                        // :209
     search2:
         if (ip + ml < mflimit)                                                                    // :212-214
             ml2 = (int)lz_hc_search(src, hc, (u32)(ip + ml - 2), (u32)(ip + 1), (u32)matchlimit, (u32)ml, true, ref2, start2);
         else ml2 = ml;
+        LZ_PROF(st, 2);
         if (ml2 == ml) {                                                                          // :216-219
             lz_seq_push(st, (u32)(ip - anchor), (u32)ml, (u32)ip - ref); ip += ml; anchor = ip;
             continue;
@@ -235,6 +286,7 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 S, u32 E, const LzHc& hc, LzSt
         if ((int)start2 + ml2 < mflimit)                                                          // :263-265
             ml3 = (int)lz_hc_search(src, hc, start2 + (u32)ml2 - 3u, start2, (u32)matchlimit, (u32)ml2, true, ref3, start3);
         else ml3 = ml2;
+        LZ_PROF(st, 3);
         if (ml3 == ml2) {                                                                         // :267-275
             if ((int)start2 < ip + ml) ml = (int)start2 - ip;
             lz_seq_push(st, (u32)(ip - anchor), (u32)ml, (u32)ip - ref); ip += ml; anchor = ip;

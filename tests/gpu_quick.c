@@ -119,9 +119,9 @@ int main(int argc, char** argv)
                 int (*dump)(unsigned long long*) = (int (*)(unsigned long long*))dlsym(RTLD_DEFAULT, "LizardGPU_profileDump");
                 unsigned long long pr[16];
                 if (dump && dump(pr) == 0) {
-                    static const char* nm[8] = { "roundA(bytes,hash,LDS,filter)", "roundB(cand wait,settle)", "extension", "glue+encode", "store drain", "container", "table init", "-" };
+                    static const char* nm[8] = { "roundA(bytes,hash,LDS,filter) | hc: rounds", "roundB(cand wait,settle) | hc: find_best", "extension | hc: wider #1", "glue+encode | hc: wider #2 + glue", "store drain", "container", "table init | hc: chain build", "-" };
                     double sum = 0; for (int k = 0; k < 8; k++) sum += (double)pr[k];   /* slots 8.. are sub-phases of the container slot */
-                    for (int k = 0; k < 7; k++) printf("    prof %-32s %6.2f %%  %.3g clk\n", nm[k], 100.0 * pr[k] / sum, (double)pr[k]);
+                    for (int k = 0; k < 7; k++) printf("    prof %-48s %6.2f %%  %.3g clk\n", nm[k], 100.0 * pr[k] / sum, (double)pr[k]);
                     {   static const char* hn[7] = { "huf histogram", "huf rank sort", "huf lane-0 tree/codes/header", "huf exact sizes", "huf bit packing", "-", "huf entry" };
                         for (int k = 8; k < 15; k++) if (pr[k]) printf("      (within container) %-28s %6.2f %%\n", hn[k - 8], 100.0 * pr[k] / sum); }
                 }

@@ -43,6 +43,30 @@ def test_emulated_kernel_long_range(level):
         assert len(out) == g["size"] and util.sha(out) == g["sha256"], (name, level)
 
 
+@pytest.mark.parametrize("level", [13, 16, 17, 35])
+def test_emulated_hashchain_vs_oracle(level):
+    """hashChain kernel (lz_hashchain.h): both hash lengths, searchNum 2/8/16/256, with and without Huffman.
+    The oracle is pinned to the compiled reference for these levels by tests/test_oracle.py."""
+    for name, data in util.corpus(small=True):
+        if level == 17 and name in ("alpha2", "alpha4"):
+            data = data[:50000]          # 256-candidate searches on 2/4-letter noise: slow under emulation
+        assert emul_compress(data, level, seed=len(name) + level) == util.oracle_compress(data, level), (name, level)
+
+
+def test_emulated_hashchain_epoch_wrap():
+    """The head table is never cleared between blocks: entries carry a 10-bit epoch and the table is
+    re-zeroed when it wraps (lz_hc_begin).  Drive one slot across the wrap with unrelated blocks."""
+    emu = util.emulator()
+    emu.emul_hc_get_epoch.restype = ctypes.c_uint
+    emu.emul_hc_set_epoch(1020)
+    seen = []
+    for i in range(6):
+        data = util.datagen(70000 + 977 * i, 0.5, 0.0, 100 + i)
+        assert emul_compress(data, 14, seed=i) == util.oracle_compress(data, 14), i
+        seen.append(emu.emul_hc_get_epoch())
+    assert seen == [1021, 1022, 1023, 1, 2, 3]
+
+
 def test_emulated_kernel_schedule_independent():
     """Output must not depend on the order lanes run between cross-lane ops (LDS store races)."""
     data = dict(util.corpus(small=True))["gen262144_p0.5"]
