@@ -32,6 +32,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+KERNEL_OF_LEVEL = {10: "lz_fast12_kernel<false>", 30: "lz_fast12_kernel<true>", 11: "lz_fast18_kernel<false>",
+                   31: "lz_fast18_kernel<true>", 21: "lz_pricefast14_kernel<false>", 41: "lz_pricefast14_kernel<true>"}
+for _l in range(13, 18):       # hashChain rows: searchLength 5 for 13-15 / 34-36, 4 for 16-17 / 37-38
+    KERNEL_OF_LEVEL[_l] = "lz_hashchain_kernel<false, %d>" % (5 if _l <= 15 else 4)
+    KERNEL_OF_LEVEL[_l + 21] = "lz_hashchain_kernel<true, %d>" % (5 if _l <= 15 else 4)
+
+
 def cpu_baseline(level, block_size, n_blocks, budget_s):
     """Time the CPU compressor on the first n_blocks blocks of rank 0's workload (host-generated with the
     same generator/seeds). Best-of-N full passes like the reference's bench (programs/bench.c:231-246)."""
@@ -200,8 +207,7 @@ def main():
             "verified_blocks_bit_exact": verified,
             "roofline": {"bound": "hbm", "achieved": round(alg_bytes / avg_k / 1e9, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(alg_bytes / avg_k / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": {10: "lz_fast12_kernel<false>", 30: "lz_fast12_kernel<true>", 21: "lz_pricefast14_kernel<false>",
-                                    41: "lz_pricefast14_kernel<true>"}.get(args.level, "?"), "avg_kernel_ms": round(avg_k * 1e3, 3),
+                         "kernel": KERNEL_OF_LEVEL.get(args.level, "?"), "avg_kernel_ms": round(avg_k * 1e3, 3),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not args.no_cpu:
