@@ -121,6 +121,54 @@ float LizardGPU_lastKernelMs(void);
 /* Number of resident waves (= blocks compressed concurrently) the launcher uses on this device. */
 int LizardGPU_residentWaves(void);
 
+/* =====================================================================================================
+ * Part 3 — one-shot frame production on the batched GPU path.
+ *
+ * LizardGPU_compressFrame() writes byte for byte what the reference's LizardF_compressFrame()
+ * (lib/lizard_frame.h:134, lib/lizard_frame.c:260-316) writes for the same preferences in
+ * independent-block mode (reference built with -DLIZARD_RESET_MEM, the zero-state oracle): frame header,
+ * LE32-sized block records (bit 31 = stored raw), end mark, XXH32 content checksum.  Every block of the
+ * frame goes through the batched kernels instead of one Lizard_compress_extState call per block.
+ * The reference keeps frame compression and decompression in ONE object (lizard_frame.c), so these
+ * symbols are prefixed LizardGPU_ and coexist with a linked reference LizardF_* (INTEGRATION.md §3).
+ *
+ * LizardGPU_framePrefs_t is layout-identical to LizardF_preferences_t (lib/lizard_frame.h:111-125): a
+ * caller holding the reference type passes (const LizardGPU_framePrefs_t*)&prefs.
+ * Return value: bytes written, or an error code that LizardGPU_frameIsError() recognises; codes are the
+ * reference's (size_t)-LizardF_ERROR_* values (lib/lizard_frame_static.h:57-67).  Refused, never emulated:
+ * linked-block frames larger than one block (blockMode_invalid) and levels without a GPU kernel
+ * (compressionLevel_invalid).
+ * ===================================================================================================== */
+typedef struct {
+    unsigned           blockSizeID;          /* LizardF_blockSizeID_t: 0 = default (128 KiB), 1..7 = 128K,256K,1M,4M,16M,64M,256M */
+    unsigned           blockMode;            /* LizardF_blockMode_t: 0 = linked, 1 = independent */
+    unsigned           contentChecksumFlag;  /* 0 / 1 */
+    unsigned           frameType;            /* 0 = frame */
+    unsigned long long contentSize;          /* != 0: the header carries srcSize */
+    unsigned           reserved[2];
+} LizardGPU_frameInfo_t;                     /* == LizardF_frameInfo_t */
+
+typedef struct {
+    LizardGPU_frameInfo_t frameInfo;
+    int      compressionLevel;               /* clamped like Lizard_createStream (lib/lizard_compress.c:303-308) */
+    unsigned autoFlush;                      /* ignored: one-shot frames always flush (lizard_frame.c:283) */
+    unsigned reserved[4];
+} LizardGPU_framePrefs_t;                    /* == LizardF_preferences_t */
+
+enum {                                       /* LizardF_errorCodes, lib/lizard_frame_static.h:57-67 */
+    LIZARDGPU_FRAME_ERR_GENERIC = 1, LIZARDGPU_FRAME_ERR_maxBlockSize_invalid = 2, LIZARDGPU_FRAME_ERR_blockMode_invalid = 3,
+    LIZARDGPU_FRAME_ERR_compressionLevel_invalid = 5, LIZARDGPU_FRAME_ERR_allocation_failed = 9,
+    LIZARDGPU_FRAME_ERR_dstMaxSize_tooSmall = 11, LIZARDGPU_FRAME_ERR_maxCode = 19
+};
+
+/* replaces LizardF_compressFrameBound, lib/lizard_frame.h:122 / lizard_frame.c:229 (same value) */
+size_t LizardGPU_compressFrameBound(size_t srcSize, const LizardGPU_framePrefs_t* preferencesPtr);
+/* replaces LizardF_compressFrame, lib/lizard_frame.h:134 / lizard_frame.c:260 (host buffers, synchronous) */
+size_t LizardGPU_compressFrame(void* dstBuffer, size_t dstMaxSize, const void* srcBuffer, size_t srcSize,
+                               const LizardGPU_framePrefs_t* preferencesPtr);
+/* replaces LizardF_isError, lib/lizard_frame.h:59 / lizard_frame.c:179 */
+unsigned LizardGPU_frameIsError(size_t code);
+
 #ifdef __cplusplus
 }
 #endif

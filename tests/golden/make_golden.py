@@ -54,6 +54,12 @@ def main():
             h = xxhash.xxh64(out.raw[:n], seed=h).intdigest()
         vec["p50_64m"][f"L{lvl}_B{bs}"] = {"sum": tot, "xxh64_chain": "%016x" % h, "first_sizes": sizes[:8]}
         print(lvl, bs, tot, "%016x" % h)
+    # frames: LizardF_compressFrame of the zero-state reference build
+    cases = dict(util.corpus())
+    vec["frames"] = {}
+    for name, case, lvl, bsid, crc, csz in util.FRAME_CASES:
+        fr = util.reference_frame(cases[case], util.frame_prefs(lvl, bsid, crc, csz))
+        vec["frames"][name] = {"size": len(fr), "sha256": util.sha(fr), "head": fr[:16].hex()}
     path = os.path.join(util.GOLDEN_DIR, "reference_vectors.json")
     with open(path, "w") as f:
         json.dump(vec, f, indent=1, sort_keys=True)

@@ -1,0 +1,137 @@
+"""Frames: LizardGPU_compressFrame must write what the reference's
+LizardF_compressFrame writes (independent blocks, zero-state build).
+
+CPU part: the golden frames (recorded from the compiled reference by tests/golden/make_golden.py) are
+reproduced by composing oracle block outputs (util.compose_frame) — this pins the composition rules,
+including the reference's 1-byte-block accident; the C library's bound, and every refusal that must happen
+before the GPU is touched, are checked through the C ABI.  GPU part (-m gpu): the library's frames equal
+the golden ones byte for byte and decode with the reference's frame decoder when it travelled."""
+import ctypes
+import json
+import os
+
+import pytest
+
+import util
+
+with open(os.path.join(util.GOLDEN_DIR, "reference_vectors.json")) as f:
+    GOLDEN = json.load(f)
+CASES = dict(util.corpus())
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from lizard_amd import _lib
+    _lib.build()
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    L.LizardGPU_compressFrameBound.restype = ctypes.c_size_t
+    L.LizardGPU_compressFrameBound.argtypes = [ctypes.c_size_t, ctypes.c_void_p]
+    L.LizardGPU_compressFrame.restype = ctypes.c_size_t
+    L.LizardGPU_compressFrame.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
+    L.LizardGPU_frameIsError.argtypes = [ctypes.c_size_t]
+    return L
+
+
+def err(code):
+    return (1 << 64) - code
+
+
+def test_composition_reproduces_golden_frames():
+    for name, case, lvl, bsid, crc, csz in util.FRAME_CASES:
+        fr = util.compose_frame(CASES[case], lvl, bsid, crc, csz, util.oracle_compress)
+        g = GOLDEN["frames"][name]
+        assert len(fr) == g["size"] and util.sha(fr) == g["sha256"] and fr[:16].hex() == g["head"], name
+
+
+def test_composition_vs_compiled_reference():
+    if util.reference() is None:
+        pytest.skip("oracle/_ref not present")
+    for name, case, lvl, bsid, crc, csz in util.FRAME_CASES:
+        want = util.reference_frame(CASES[case], util.frame_prefs(lvl, bsid, crc, csz))
+        assert util.compose_frame(CASES[case], lvl, bsid, crc, csz, util.oracle_compress) == want, name
+    # multi-block with every block size id that is cheap on the CPU
+    data = util.datagen(3 * (1 << 20) + 4321, 0.5, 0.0, 8)
+    for bsid in (1, 2, 3, 4):
+        want = util.reference_frame(data, util.frame_prefs(10, bsid, 1, 1))
+        assert util.compose_frame(data, 10, bsid, 1, 1, util.oracle_compress) == want, bsid
+
+
+def test_frame_bound_matches_reference_formula(lib):
+    ref = util.reference()
+    for n in (0, 1, 131071, 131072, 131073, 262144, 1 << 20, (4 << 20) + 5, 100 << 20):
+        for bsid in range(0, 8):
+            for crc in (0, 1):
+                p = util.frame_prefs(10, bsid, crc, 0)
+                got = lib.LizardGPU_compressFrameBound(n, ctypes.byref(p))
+                if ref is not None:
+                    util._reference_frame_fn(ref)
+                    assert got == ref.LizardF_compressFrameBound(n, ctypes.byref(p)), (n, bsid, crc)
+                assert got >= 15 + 4 + n + 4
+    assert lib.LizardGPU_compressFrameBound(1000, None) == 15 + 4 + 1000 + 4          # NULL prefs: defaults, no checksum
+    bad = util.frame_prefs(10, 9, 0, 0)
+    assert lib.LizardGPU_frameIsError(lib.LizardGPU_compressFrameBound(1 << 30, ctypes.byref(bad)))
+
+
+def test_frame_refusals_need_no_gpu(lib):
+    data = util.datagen(300000, 0.5, 0.0, 1)
+    cap = 400000
+    dst = ctypes.create_string_buffer(cap)
+    # linked blocks over more than one block: serial, stays on the reference
+    p = util.frame_prefs(10, 1, 0, 0, block_mode=0)
+    assert lib.LizardGPU_compressFrame(dst, cap, data, len(data), ctypes.byref(p)) == err(3)
+    # destination below the bound (lizard_frame.c:289)
+    p = util.frame_prefs(10, 1, 0, 0)
+    assert lib.LizardGPU_compressFrame(dst, 1000, data, len(data), ctypes.byref(p)) == err(11)
+    # a level without a GPU kernel is refused, not emulated
+    p = util.frame_prefs(12, 1, 0, 0)
+    assert lib.LizardGPU_compressFrame(dst, cap, data, len(data), ctypes.byref(p)) == err(5)
+    assert lib.LizardGPU_frameIsError(err(5)) and not lib.LizardGPU_frameIsError(12345)
+
+
+@pytest.mark.gpu
+def test_gpu_frames_equal_reference_frames(lib):
+    for name, case, lvl, bsid, crc, csz in util.FRAME_CASES:
+        data = CASES[case]
+        p = util.frame_prefs(lvl, bsid, crc, csz)
+        cap = lib.LizardGPU_compressFrameBound(len(data), ctypes.byref(p))
+        dst = ctypes.create_string_buffer(cap)
+        n = lib.LizardGPU_compressFrame(dst, cap, data, len(data), ctypes.byref(p))
+        assert not lib.LizardGPU_frameIsError(n), (name, n - (1 << 64))
+        g = GOLDEN["frames"][name]
+        assert n == g["size"] and util.sha(dst.raw[:n]) == g["sha256"], name
+
+
+@pytest.mark.gpu
+def test_gpu_frame_many_blocks_roundtrip(lib):
+    """64 MiB + ragged tail in 256 KiB blocks: equals the oracle composition; decodes with the reference
+    frame decoder when oracle/_ref travelled."""
+    data = util.datagen((64 << 20) + 77777, 0.5, 0.0, 21)
+    p = util.frame_prefs(10, 2, 1, 1)
+    cap = lib.LizardGPU_compressFrameBound(len(data), ctypes.byref(p))
+    dst = ctypes.create_string_buffer(cap)
+    n = lib.LizardGPU_compressFrame(dst, cap, data, len(data), ctypes.byref(p))
+    assert not lib.LizardGPU_frameIsError(n)
+    assert dst.raw[:n] == util.compose_frame(data, 10, 2, 1, 1, util.oracle_compress)
+    ref = util.reference()
+    if ref is not None:
+        dctx = ctypes.c_void_p()
+        ref.LizardF_createDecompressionContext.argtypes = [ctypes.c_void_p, ctypes.c_uint]
+        ref.LizardF_createDecompressionContext.restype = ctypes.c_size_t
+        assert ref.LizardF_createDecompressionContext(ctypes.byref(dctx), 100) == 0
+        ref.LizardF_decompress.restype = ctypes.c_size_t
+        ref.LizardF_decompress.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p,
+                                           ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p]
+        back = ctypes.create_string_buffer(len(data))
+        src = ctypes.create_string_buffer(dst.raw[:n], n)
+        so, do = 0, 0
+        while so < n:
+            ds, ss = ctypes.c_size_t(len(data) - do), ctypes.c_size_t(n - so)
+            r = ref.LizardF_decompress(dctx, ctypes.byref(back, do), ctypes.byref(ds), ctypes.byref(src, so), ctypes.byref(ss), None)
+            assert r < (1 << 63), "frame decoder error"
+            so += ss.value
+            do += ds.value
+            if r == 0:
+                break
+        assert do == len(data) and back.raw == data
+        ref.LizardF_freeDecompressionContext.argtypes = [ctypes.c_void_p]
+        ref.LizardF_freeDecompressionContext(dctx)

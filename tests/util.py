@@ -164,3 +164,99 @@ def corpus_long():
     out.append(("p50_4m", datagen(4 << 20, 0.5, 0.0, 5)))
     out.append(("p20_2m", datagen(2 << 20, 0.2, 0.0, 6)))
     return out
+
+
+# ---- frames (lizard_frame.h:111-125 LizardF_preferences_t == LizardGPU_framePrefs_t) -------------------
+class FrameInfo(ctypes.Structure):
+    _fields_ = [("blockSizeID", ctypes.c_uint), ("blockMode", ctypes.c_uint), ("contentChecksumFlag", ctypes.c_uint),
+                ("frameType", ctypes.c_uint), ("contentSize", ctypes.c_ulonglong), ("reserved", ctypes.c_uint * 2)]
+
+
+class FramePrefs(ctypes.Structure):
+    _fields_ = [("frameInfo", FrameInfo), ("compressionLevel", ctypes.c_int), ("autoFlush", ctypes.c_uint),
+                ("reserved", ctypes.c_uint * 4)]
+
+
+FRAME_BLOCK_SIZES = {0: 128 << 10, 1: 128 << 10, 2: 256 << 10, 3: 1 << 20, 4: 4 << 20, 5: 16 << 20, 6: 64 << 20, 7: 256 << 20}
+
+
+def frame_prefs(level, bsid=0, checksum=0, content_size=0, block_mode=1):
+    p = FramePrefs()
+    p.frameInfo.blockSizeID = bsid
+    p.frameInfo.blockMode = block_mode
+    p.frameInfo.contentChecksumFlag = checksum
+    p.frameInfo.contentSize = content_size
+    p.compressionLevel = level
+    return p
+
+
+FRAME_CASES = [
+    # (name, corpus case, level, blockSizeID, checksum, contentSize flag)
+    ("empty_default", "gen0_p0.5", 10, 0, 0, 0),
+    ("empty_crc", "gen0_p0.5", 10, 2, 1, 1),
+    ("one_byte", "gen1_p0.5", 10, 0, 1, 0),
+    ("ragged_128k", "gen131073_p0.5", 10, 1, 1, 0),
+    ("ragged_128k_L30", "gen131073_p0.5", 30, 1, 1, 1),
+    ("256k_bs256k", "gen262144_p0.5", 10, 2, 1, 0),
+    ("zeros_default_level", "zeros300k", 0, 1, 0, 0),          # level 0 -> 17 (lizard_compress.c:303-308)
+    ("noise_raw_blocks", "random256k", 10, 1, 1, 0),
+    ("text_L21", "text", 21, 1, 0, 1),
+    ("text_L41_big_id", "text", 41, 4, 1, 0),                  # optimal block size id shrinks to the input
+    ("alpha4_L13", "alpha4", 13, 1, 1, 0),
+    ("period65_L11", "period65", 11, 1, 0, 0),
+]
+
+
+def _reference_frame_fn(ref):
+    ref.LizardF_compressFrameBound.restype = ctypes.c_size_t
+    ref.LizardF_compressFrameBound.argtypes = [ctypes.c_size_t, ctypes.c_void_p]
+    ref.LizardF_compressFrame.restype = ctypes.c_size_t
+    ref.LizardF_compressFrame.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
+    return ref
+
+
+def reference_frame(data, prefs):
+    """LizardF_compressFrame of the compiled reference (zero-state build); None when oracle/_ref is absent."""
+    ref = reference()
+    if ref is None:
+        return None
+    _reference_frame_fn(ref)
+    cap = ref.LizardF_compressFrameBound(len(data), ctypes.byref(prefs))
+    dst = ctypes.create_string_buffer(cap)
+    n = ref.LizardF_compressFrame(dst, cap, data, len(data), ctypes.byref(prefs))
+    assert n <= cap, "reference frame error %d" % (n - (1 << 64))
+    return dst.raw[:n]
+
+
+def compose_frame(data, level, bsid, checksum, content_size_flag, compress_block):
+    """Restatement of LizardF_compressFrame (lib/lizard_frame.c:260-316, :403-424, :456-469, :651-658) for
+    independent blocks, on top of any block compressor `compress_block(bytes, level) -> bytes`."""
+    import struct
+    import xxhash
+    n = len(data)
+    proposed, req = 1, bsid
+    while req > proposed:                                   # LizardF_optimalBSID
+        if n <= FRAME_BLOCK_SIZES[proposed]:
+            req = proposed
+            break
+        proposed += 1
+    bsid = req if req else 1
+    bs = FRAME_BLOCK_SIZES[bsid]
+    lvl = min(level, 49)
+    if lvl < 10:
+        lvl = 17
+    hdr = bytes([(1 << 6) + (1 << 5) + (checksum << 2) + ((1 if (content_size_flag and n) else 0) << 3), bsid << 4])
+    if content_size_flag and n:
+        hdr += struct.pack("<Q", n)
+    out = struct.pack("<I", 0x184D2206) + hdr + bytes([(xxhash.xxh32(hdr, seed=0).intdigest() >> 8) & 255])
+    for off in range(0, n, bs):
+        blk = data[off:off + bs]
+        c = compress_block(blk, lvl)
+        if len(c) > len(blk) - 1 and len(blk) != 1:      # 1-byte blocks: the room test of lizard_compress.c:238 wraps
+            out += struct.pack("<I", len(blk) | 0x80000000) + blk
+        else:
+            out += struct.pack("<I", len(c)) + c
+    out += struct.pack("<I", 0)
+    if checksum:
+        out += struct.pack("<I", xxhash.xxh32(data, seed=0).intdigest())
+    return out
