@@ -38,19 +38,22 @@ struct LzBatch {
 #endif
 #define LZ_WAVES_FAST      13
 #define LZ_WAVES_FAST_HUF  9
-#define LZ_WAVES_PF        3
 
-template <int PARSER, int HASHLOG, int AUX, bool HUF, int W, int WSWORDS>
+// NLDS of the W waves keep their hash table in LDS, the others in the wave's global-memory slot (a.tables).
+template <int PARSER, int HASHLOG, int AUX, bool HUF, int W, int WSWORDS, int NLDS = (HASHLOG > 14 ? 0 : W)>
 __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
 {
-    constexpr bool kGlobalTable = HASHLOG > 14;                      // hashLog 18 (levels 11/31, hashChain): 1 MiB per wave, not LDS
-    struct Slice { u32 table[kGlobalTable ? 1 : LZ_TAB_BYTES(HASHLOG) / 4u]; u64 ring[PARSER != LZ_PARSER_PRICEFAST ? LZ_SEQ_RING : 1]; u32 ws[WSWORDS]; };
+    struct Slice { u64 ring[PARSER != LZ_PARSER_PRICEFAST ? LZ_SEQ_RING : 1]; u32 ws[WSWORDS]; };
+    __shared__ u32 ldsTables[NLDS ? NLDS : 1][NLDS ? LZ_TAB_BYTES(HASHLOG) / 4u : 1];
     __shared__ Slice lds[W];
     const u32 wave = threadIdx.x >> 6;
     Slice& my = lds[wave];
     const u64 slot = (u64)blockIdx.x * W + wave;
     u8* scratch = a.scratch + slot * LZ_SCRATCH_BYTES;
-    void* tableMem = kGlobalTable ? (void*)(a.tables + slot * a.tableStride) : (void*)my.table;
+    void* tableMem;
+    if constexpr (NLDS == W)      tableMem = (void*)ldsTables[wave];
+    else if constexpr (NLDS == 0) tableMem = (void*)(a.tables + slot * a.tableStride);
+    else tableMem = wave < (u32)NLDS ? (void*)ldsTables[wave] : (void*)(a.tables + slot * a.tableStride);   // generic pointer: flat accesses
     for (;;) {
         lz_converge();
         const u32 b = lz_claim_index(a.counter);
@@ -87,11 +90,18 @@ __global__ __launch_bounds__(64 * LZ_WAVES_HC) void lz_hashchain_kernel(LzBatch 
     lz_wave_main<LZ_PARSER_HASHCHAIN, 18, SEARCHLEN, HUF, LZ_WAVES_HC, (HUF ? LZ_HUF_WS_WORDS : (1u << LZ_HC_TAGLOG) / 4u)>(a);
 }
 
-// levels 21 / 41: priceFast + LIZv1, 2^14-slot table (24-bit slots, 48 KiB) + round tag array / Huffman workspace
+// levels 21 / 41: priceFast + LIZv1, 2^14-slot table of 24-bit positions (48 KiB).  Only three such tables fit a
+// CU's LDS, and the parse is a latency chain, so the workgroup carries 16 waves anyway: NLDS of them keep the
+// table in LDS, the others in their global-memory slot (L2 / Infinity Cache; ~5x slower per wave, but there are
+// many more of them).  LDS: 2 x 48 KiB + 16 x 2 KiB tag arrays (level 21), 1 x 48 KiB + 16 x 5.3 KiB Huffman
+// workspaces (level 41).
+#define LZ_WAVES_PF 16
+#define LZ_PF_TAGLOG 11
+#define LZ_PF_SLOT_BYTES 65536u
 template <bool HUF>
 __global__ __launch_bounds__(64 * LZ_WAVES_PF) void lz_pricefast14_kernel(LzBatch a)
 {
-    lz_wave_main<LZ_PARSER_PRICEFAST, 14, 12, HUF, LZ_WAVES_PF, (HUF ? LZ_HUF_WS_WORDS : 1024)>(a);
+    lz_wave_main<LZ_PARSER_PRICEFAST, 14, LZ_PF_TAGLOG, HUF, LZ_WAVES_PF, (HUF ? LZ_HUF_WS_WORDS : (1u << LZ_PF_TAGLOG) / 4u), (HUF ? 1 : 2)>(a);
 }
 
 // synthetic input: one thread per block, block b = RDG_genBuffer(blockSize, P, seed0 + b)
@@ -110,6 +120,7 @@ struct Ctx {
     int   wavesHuf = 0;         // persistent grid size (level 30: larger LDS workspace)
     int   wavesPf = 0, wavesPfHuf = 0;   // levels 21 / 41
     u8*   tables = nullptr;     // levels 11 / 31, allocated on first use
+    u8*   pfTables = nullptr;   // levels 21 / 41: 64 KiB per resident wave for the waves whose table is not in LDS
     u8*   hcSlots = nullptr;    // hashChain levels, allocated (and zeroed) on first use / when a larger block size arrives
     size_t hcMaxBlock = 0;
     u8*   scratch = nullptr;
@@ -212,6 +223,10 @@ int launch_locked(const void* d_src, size_t nBlocks, size_t blockSize, size_t la
             LZ_HIP(hipMalloc((void**)&g_ctx.tables, (size_t)g_ctx.cus * LZ_WAVES_FAST18 * LZ_TABWIDE_BYTES(18)));
             a.tables = g_ctx.tables;
         }
+    }
+    if (lv == 21 || lv == 41) {
+        if (!g_ctx.pfTables) LZ_HIP(hipMalloc((void**)&g_ctx.pfTables, (size_t)g_ctx.cus * LZ_WAVES_PF * LZ_PF_SLOT_BYTES));
+        a.tables = g_ctx.pfTables; a.tableStride = LZ_PF_SLOT_BYTES;
     }
     u32 grid = (u32)((nBlocks + W - 1) / W);
     if (grid > (u32)g_ctx.cus) grid = (u32)g_ctx.cus;
