@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64 * (HUF ? LZ_WAVES_FAST_HUF : LZ_WAVES_FAST)) voi
 template <bool HUF>
 __global__ __launch_bounds__(64 * LZ_WAVES_FAST18) void lz_fast18_kernel(LzBatch a)
 {
-    lz_wave_main<LZ_PARSER_FAST, 18, 0, HUF, LZ_WAVES_FAST18, (HUF ? LZ_HUF_WS_WORDS : 1)>(a);
+    lz_wave_main<LZ_PARSER_FAST, 18, 0, HUF, LZ_WAVES_FAST18, (HUF ? LZ_HUF_WS_WORDS : (1u << LZ_WIDE_TAGLOG) / 4u)>(a);
 }
 
 // levels 13-17 / 34-38: hashChain parser (searchLength 5 for rows 13-15, 4 for 16-17; searchNum comes from the

@@ -281,6 +281,7 @@ LZ_DEV void lz_emit_last_literals(const u8* src, u32 anchor, u32 E, LzStreams& s
 struct LzTab {
     u16* lo; u8* hi;
     static constexpr bool kSweeps = true;
+    static constexpr bool kTagDedup = false;
     LZ_DEVM u32  entry(u32 p, u32 first4) const { return (p & 0x1FFFFu) | ((first4 * 2654435761u) >> 25 << 17); }
     LZ_DEVM u32  get(u32 h) const { return (u32)lo[h] | ((u32)hi[h] << 16); }
     LZ_DEVM void set(u32 h, u32 ent) const { lo[h] = (u16)ent; hi[h] = (u8)(ent >> 16); }
@@ -306,12 +307,18 @@ LZ_DEV void lz_tab_sweep(const LzTab& t, u32 Ps, bool fresh)
 }
 template <int HASHLOG> LZ_DEV void lz_tab_fresh(const LzTab& t) { lz_tab_sweep<HASHLOG>(t, 0, true); }
 
-// Wide variant for tables that do not fit LDS (hashLog 18: levels 11/31; 1 MiB per wave in global memory,
-// L2/Infinity-Cache resident): u32 slots, bits 0..21 = position (blocks up to 4 MiB), bits 22..31 = check
-// hash, 0xFFFFFFFF = empty.  Full positions need no sweep; cross-lane ordering needs the full wave sync.
+// Wide variant for tables that do not fit LDS (hashLog 18: levels 11/31; 1 MiB per wave in global memory —
+// 4 GiB over the resident waves, so every access is a random HBM sector): u32 slots, bits 0..21 = position
+// (blocks up to 4 MiB), bits 22..31 = check hash, 0xFFFFFFFF = empty.  Full positions need no sweep;
+// cross-lane ordering needs the full wave sync.  Table accesses are what a round costs here, so same-slot
+// lanes of a round are found through a small LDS tag array (as in lz_pricefast.h) instead of put + read-back,
+// and nothing is stored speculatively: one gather and one scatter per round.
+#define LZ_WIDE_TAGLOG 11
 struct LzTabWide {
     u32* w;
+    u8* tag;                                                                     // LDS, 2^LZ_WIDE_TAGLOG bytes
     static constexpr bool kSweeps = false;
+    static constexpr bool kTagDedup = true;
     LZ_DEVM u32  entry(u32 p, u32 first4) const { return p | ((first4 * 2654435761u) >> 22 << 22); }
     LZ_DEVM u32  get(u32 h) const { return w[h]; }
     LZ_DEVM void set(u32 h, u32 ent) const { w[h] = ent; }
@@ -397,11 +404,20 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
             const u32 h = lz_hash5<HASHLOG>(bytes);
             const u32 mine = table.entry(p, first4);
             u32 e = table.get(h);                                        // fast.h:86 (value before this round)
-            lz_converge();                                               // every lane has read before any lane puts
-            table.set(valid ? h : (1u << HASHLOG), mine);                // speculative put (fast.h:88); undone below if needed
-            table.sync();
-            // two slots of this round on one table slot: the later must see the earlier's put, in order
-            const bool lost = valid && table.lostPut(h, mine);
+            bool lost;
+            if constexpr (TAB::kTagDedup) {                              // same-slot lanes found through LDS; nothing stored yet
+                const u32 ti = h & ((1u << LZ_WIDE_TAGLOG) - 1u);
+                if (valid) table.tag[ti] = (u8)lane;
+                lz_lds_sync();
+                lost = valid && table.tag[ti] != (u8)lane;
+                lz_lds_sync();                                           // reads done before the next round's writes
+            } else {
+                lz_converge();                                           // every lane has read before any lane puts
+                table.set(valid ? h : (1u << HASHLOG), mine);            // speculative put (fast.h:88); undone below if needed
+                table.sync();
+                // two slots of this round on one table slot: the later must see the earlier's put, in order
+                lost = valid && table.lostPut(h, mine);
+            }
             u64 pend = lz_ballot(lost);                                  // uniform
             u64 grp = laneBit;                                           // lanes of this round on my table slot
             const u32 eOld = e;
@@ -459,7 +475,10 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
             u64 commit = validMask;
             if (okMask) { w = lz_ctz64(okMask); commit = validMask & (~0ull >> (63u - w)); }
             // settle the table slots: slots after the winner never happened (the reference stopped there)
-            {
+            if constexpr (TAB::kTagDedup) {                              // last committed slot of every group stores, once
+                const u64 c = grp & commit;
+                table.set((valid && (c >> lane) == 1ull) ? h : (1u << HASHLOG), mine);
+            } else {
                 const u64 c = grp & commit;                              // committed slots on my table slot
                 const bool single = grp == laneBit;
                 const bool undo = single ? !(commit & laneBit)           // my own put did not happen
@@ -646,7 +665,7 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
     // fast parser: 24-bit LDS slots up to hashLog 14, wide u32 slots in global memory above; priceFast: 24-bit LDS slots
     constexpr bool kWide = PARSER == LZ_PARSER_FAST && HASHLOG > 14;
     LzTab tab = lz_tab_bind<kWide ? 1 : HASHLOG>(tableMem);
-    LzTabWide tabw; tabw.w = (u32*)tableMem;
+    LzTabWide tabw; tabw.w = (u32*)tableMem; tabw.tag = ws;
     LzHc hc;
     if constexpr (PARSER == LZ_PARSER_HASHCHAIN) {
         const u32 row = (level >= 30u ? level - 21u : level) - 13u;                  // lizard_common.h:240-244, :264-268
