@@ -146,6 +146,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const LzTab& table, 
             ip += lz_popc64(validMask);                          // "ip++" for every probed position, :173
         }
         // ---------------- winner: lengths, lazy re-search, encode ----------------
+        LZ_PROF(st, 0);                                          // search rounds
         {
             u32 ml = 4u + lz_count_fwd(src, P + 4u, M + 4u, matchlimit);
             u32 ml2 = 0, start2 = 0, ref2 = 0, ref = M;
@@ -156,6 +157,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const LzTab& table, 
                 ip -= back; ref -= back; ml += back;
             }
         search:
+            LZ_PROF(st, 2);                                      // winner lengths / arbitration
             if (ip + ml >= mflimit) goto encode;                                          // :185
             start2 = ip + ml - 2u;
             {
@@ -171,6 +173,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const LzTab& table, 
                 if (lane == 0 && (e2 >= start2 || start2 >= e2 + LZ_MIN_OFFSET)) lz_tab_set(table, h2, start2);   // :190-191
                 lz_wave_sync();
             }
+            LZ_PROF(st, 1);                                      // lazy re-search (table get/set, candidate, count)
             if (!ml2) goto encode;
             {
                 const u32 back = lz_count_back(src, start2, ref2, ip);                    // :195-201
@@ -186,7 +189,9 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const LzTab& table, 
                 if (ml2 < LZ_MM_LONGOFF && start2 - ref2 >= LZ_16BIT_OFFSET) ml2 = 0;
             }
         encode:
+            LZ_PROF(st, 2);
             lz_emit_lizv1(src, anchor, ip, ml, ref, st, last_off);                        // :231
+            LZ_PROF(st, 3);                                      // LIZv1 encode into the staging areas
             ip += ml; anchor = ip;
             if (ml2) { ip = start2; ref = ref2; ml = ml2; ml2 = 0; goto search; }         // :233-238
         }
