@@ -53,14 +53,15 @@ __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
     void* tableMem;
     if constexpr (NLDS == W)      tableMem = (void*)ldsTables[wave];
     else if constexpr (NLDS == 0) tableMem = (void*)(a.tables + slot * a.tableStride);
-    else tableMem = wave < (u32)NLDS ? (void*)ldsTables[wave] : (void*)(a.tables + slot * a.tableStride);   // generic pointer: flat accesses
+    else tableMem = wave < (u32)NLDS ? (void*)ldsTables[wave] : (void*)(a.tables + slot * a.tableStride);   // (priceFast: u32 slots there)
     for (;;) {
         lz_converge();
         const u32 b = lz_claim_index(a.counter);
         if (b >= a.nBlocks) break;
         const u32 n = (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
         const u32 c = lz_compress_block<PARSER, HASHLOG, AUX, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
-                                                                  a.level, tableMem, (u8*)my.ws, scratch, my.ring);
+                                                                  a.level, tableMem, (u8*)my.ws, scratch, my.ring,
+                                                                  PARSER == LZ_PARSER_PRICEFAST && NLDS != W && wave >= (u32)NLDS);
         if (lz_lane() == 0) a.sizes[b] = c;
         lz_converge();
     }

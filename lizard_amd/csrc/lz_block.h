@@ -139,6 +139,30 @@ LZ_DEV u32 lz_count_back(const u8* src, u32 P, u32 M, u32 anchor)
     }
 }
 
+// Forward count from offset 0 and backward extension of one candidate pair (P > M, uniform) with their
+// loads in flight together: one round trip instead of two whenever the match is shorter than 512 bytes and
+// the extension shorter than 64.  fwd = lz_count_fwd(src, P, M, limit), back = lz_count_back(src, P, M, anchor).
+LZ_DEV void lz_count_both(const u8* src, u32 P, u32 M, u32 limit, u32 anchor, u32& fwd, u32& back)
+{
+    const u32 lane = lz_lane();
+    const u32 i = 8u * lane, j = lane + 1u;
+    const bool inF = P + i < limit, inB = (P >= anchor + j) && (M >= j);
+    const u64 x = lz_ld64(src + (inF ? P + i : P)) ^ lz_ld64(src + (inF ? M + i : M));
+    const u32 bp = src[inB ? P - j : P], bm = src[inB ? M - j : P];
+    u32 c = 0;
+    if (inF) {
+        const u32 room = limit - (P + i);
+        c = x ? lz_ctz64(x) >> 3 : 8u;
+        c = c < room ? c : room;
+    }
+    const u64 stop = lz_ballot(c < 8u);
+    const u64 ne = lz_ballot(!(inB && bp == bm));
+    if (stop) { const u32 f = lz_ctz64(stop); fwd = 8u * f + lz_readlane(c, f); }
+    else fwd = 512u + lz_count_fwd(src, P + 512u, M + 512u, limit);
+    if (ne) back = lz_ctz64(ne);
+    else back = 64u + lz_count_back(src, P - 64u, M - 64u, anchor);
+}
+
 // Wave-wide byte copy (all lanes call; n uniform). dst/src need no alignment.
 LZ_DEV void lz_copy(u8* dst, const u8* src, u32 n)
 {
@@ -297,6 +321,11 @@ struct LzTab {
 template <int HASHLOG> LZ_DEV LzTab lz_tab_bind(void* mem) { LzTab t; t.lo = (u16*)mem; t.hi = (u8*)mem + (2u << HASHLOG) + 2u; return t; }
 LZ_DEV u32 lz_tab_get(const LzTab& t, u32 h) { return t.get(h); }
 LZ_DEV void lz_tab_set(const LzTab& t, u32 h, u32 ent) { t.set(h, ent); }
+// The same 24-bit values in u32 slots, for tables kept in global memory: every access there is a random
+// memory sector, and the split u16 + u8 layout would cost two of them per get and per set.
+struct LzTab32 { u32* w; };
+LZ_DEV u32 lz_tab_get(const LzTab32& t, u32 h) { return t.w[h]; }
+LZ_DEV void lz_tab_set(const LzTab32& t, u32 h, u32 ent) { t.w[h] = ent; }
 // Re-stamp every slot that is dead at position Ps (age >= 65536); with `fresh`: all empty.
 template <int HASHLOG>
 LZ_DEV void lz_tab_sweep(const LzTab& t, u32 Ps, bool fresh)
@@ -642,7 +671,8 @@ LZ_DEV u32 lz_write_subblock_fast(const u8* src, u32 S, u32 E, u8* op, LzStreams
 // ---- one API block: reference Lizard_compress_extState on a zeroed state (lizard_compress.c:583) ----
 // dst must have room for Lizard_compressBound(n) bytes. Returns the compressed size (uniform).
 // seqRing:  fast parser -> LZ_SEQ_RING u64 of LDS (may be null for priceFast).
-// tableMem: LZ_TAB_BYTES(HASHLOG) bytes (24-bit slots, see LzTab); fast parser with HASHLOG > 14:
+// tableMem: LZ_TAB_BYTES(HASHLOG) bytes (24-bit slots, see LzTab) — priceFast with tab32: 4 << HASHLOG bytes of
+//           u32 slots (LzTab32, for tables in global memory); fast parser with HASHLOG > 14:
 //           LZ_TABWIDE_BYTES(HASHLOG) bytes of 16-byte aligned global memory (LzTabWide, blocks <= 4 MiB).
 // AUX:      priceFast only -> TAGLOG of the round tag array.
 //           hashChain -> searchLength (4 or 5); tableMem = the wave's LZ_HC_SLOT_BYTES slot (global, zeroed once by
@@ -652,7 +682,8 @@ LZ_DEV u32 lz_write_subblock_fast(const u8* src, u32 S, u32 E, u8* op, LzStreams
 #define LZ_PARSER_PRICEFAST 1
 #define LZ_PARSER_HASHCHAIN 2
 template <int PARSER, int HASHLOG, int AUX, bool HUF>
-LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tableMem, u8* ws, u8* scratch, u64* seqRing)
+LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tableMem, u8* ws, u8* scratch, u64* seqRing,
+                             bool tab32 = false)
 {
     const u32 lane = lz_lane();
     LzStreams st;
@@ -674,6 +705,7 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
     }
     else if constexpr (kWide) lz_tab_fresh<HASHLOG>(tabw);
     else if constexpr (PARSER == LZ_PARSER_FAST) { lz_tab_fresh<HASHLOG>(tab); st.sweepAt = 32768u; }
+    else if (tab32) { LzTab32 t32; t32.w = (u32*)tableMem; for (u32 i = lane; i < (1u << HASHLOG); i += 64u) lz_tab_set(t32, i, LZ_EMPTY24); }
     else for (u32 i = lane; i < (1u << HASHLOG); i += 64u) lz_tab_set(tab, i, LZ_EMPTY24);
     lz_wave_sync();
     LZ_PROF(st, 6);                                           // table init
@@ -687,6 +719,7 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
         if constexpr (PARSER == LZ_PARSER_HASHCHAIN) lz_parse_hashchain(src, pos, pos + part, hc, st);
         else if constexpr (kWide)                    lz_parse_fast<HASHLOG>(src, pos, pos + part, tabw, st);
         else if constexpr (PARSER == LZ_PARSER_FAST) lz_parse_fast<HASHLOG>(src, pos, pos + part, tab, st);
+        else if (tab32) { LzTab32 t32; t32.w = (u32*)tableMem; lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, t32, ws, st); }
         else                                    lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, tab, ws, st);
         if constexpr (kSeqList)                 op += lz_write_subblock_fast<HUF>(src, pos, pos + part, dst + op, st, (u32*)ws);
         else if constexpr (HUF)                 op += lz_write_subblock_huf(src + pos, part, dst + op, st, (u32*)ws);

@@ -68,11 +68,12 @@ LZ_DEV void lz_emit_lizv1(const u8* src, u32 anchor, u32 P, u32 ml, u32 M, LzStr
 // Sub-block [S,E) of the block at src. windowLog 22 / minMatchLongOff 16 are the level-21/22 values
 // (lizard_common.h:249-250).  table: 2^HASHLOG positions (LZ_EMPTY = never written); tag: 2^TAGLOG bytes.
 // Table: 2^HASHLOG slots of 24 bits (u16 + u8 arrays, LzTab without check bits) holding block-relative
-// positions, LZ_EMPTY24 when never written: 48 KiB of LDS at HASHLOG 14 instead of 64 KiB -> 3 waves per CU.
+// positions, LZ_EMPTY24 when never written: 48 KiB of LDS at HASHLOG 14; or the same values in u32 slots
+// (LzTab32) when the table lives in global memory.
 // Positions must stay below 2^24 - 1: blocks up to 16 MiB (the launcher refuses larger ones at these levels).
 #define LZ_EMPTY24 0xFFFFFFu
-template <int HASHLOG, int TAGLOG>
-LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const LzTab& table, u8* tag, LzStreams& st)
+template <int HASHLOG, int TAGLOG, class TAB>
+LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8* tag, LzStreams& st)
 {
     const u32 lane = lz_lane();
     const u64 laneBit = 1ull << lane;
@@ -148,14 +149,12 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const LzTab& table, 
         // ---------------- winner: lengths, lazy re-search, encode ----------------
         LZ_PROF(st, 0);                                          // search rounds
         {
-            u32 ml = 4u + lz_count_fwd(src, P + 4u, M + 4u, matchlimit);
-            u32 ml2 = 0, start2 = 0, ref2 = 0, ref = M;
+            u32 ml, back0;
+            lz_count_both(src, P, M, matchlimit, anchor, ml, back0);                      // both lengths, one round trip
+            u32 ml2 = 0, start2 = 0, ref2 = 0, ref = M, back2 = 0;
             ip = P;
             if (ip - ref == last_off) { ref = ip; goto encode; }                          // :174 -> repeat offset, no lazy step
-            {
-                const u32 back = lz_count_back(src, ip, ref, anchor);                     // :176-182
-                ip -= back; ref -= back; ml += back;
-            }
+            ip -= back0; ref -= back0; ml += back0;                                       // :176-182
         search:
             LZ_PROF(st, 2);                                      // winner lengths / arbitration
             if (ip + ml >= mflimit) goto encode;                                          // :185
@@ -164,10 +163,11 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const LzTab& table, 
                 const u32 h2 = lz_hash5<HASHLOG>(lz_ld64(src + start2));
                 const u32 e2 = lz_tab_get(table, h2);
                 const u32 low2 = start2 > maxDist ? start2 - maxDist : 0u;
-                ml2 = 0;
-                if (e2 < start2 && e2 >= low2 && start2 - e2 >= LZ_MIN_OFFSET && lz_ld32(src + e2) == lz_ld32(src + start2)) {   // :106-110
-                    const u32 mlt = 4u + lz_count_fwd(src, start2 + 4u, e2 + 4u, matchlimit);
-                    if (mlt >= LZ_MM_LONGOFF || start2 - e2 < LZ_16BIT_OFFSET) { ml2 = mlt; ref2 = e2; }       // :112
+                ml2 = 0; back2 = 0;
+                if (e2 < start2 && e2 >= low2 && start2 - e2 >= LZ_MIN_OFFSET) {                            // :106-110
+                    u32 mlt;                                                      // 4-byte test, length and :195-201 in one round trip
+                    lz_count_both(src, start2, e2, matchlimit, ip, mlt, back2);
+                    if (mlt >= 4u && (mlt >= LZ_MM_LONGOFF || start2 - e2 < LZ_16BIT_OFFSET)) { ml2 = mlt; ref2 = e2; }   // :112
                 }
                 lz_wave_sync();
                 if (lane == 0 && (e2 >= start2 || start2 >= e2 + LZ_MIN_OFFSET)) lz_tab_set(table, h2, start2);   // :190-191
@@ -175,10 +175,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const LzTab& table, 
             }
             LZ_PROF(st, 1);                                      // lazy re-search (table get/set, candidate, count)
             if (!ml2) goto encode;
-            {
-                const u32 back = lz_count_back(src, start2, ref2, ip);                    // :195-201
-                start2 -= back; ref2 -= back; ml2 += back;
-            }
+            start2 -= back2; ref2 -= back2; ml2 += back2;                                 // :195-201
             if (ml2 <= ml) { ml2 = 0; goto encode; }                                      // :203
             if (start2 <= ip) { ip = start2; ref = ref2; ml = ml2; ml2 = 0; goto encode; }            // :205-210
             if (start2 - ip < 3u) { ip = start2; ref = ref2; ml = ml2; ml2 = 0; goto search; }        // :212-217
