@@ -46,7 +46,7 @@ __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
     struct Slice { u64 ring[PARSER != LZ_PARSER_PRICEFAST ? LZ_SEQ_RING : 1]; u32 ws[WSWORDS]; };
     __shared__ u32 ldsTables[NLDS ? NLDS : 1][NLDS ? LZ_TAB_BYTES(HASHLOG) / 4u : 1];
     __shared__ Slice lds[W];
-    const u32 wave = threadIdx.x >> 6;
+    const u32 wave = lz_uniform(threadIdx.x >> 6);               // readfirstlane: the wave index (and everything derived from it) lives in SGPRs
     Slice& my = lds[wave];
     const u64 slot = (u64)blockIdx.x * W + wave;
     u8* scratch = a.scratch + slot * LZ_SCRATCH_BYTES;
