@@ -36,8 +36,10 @@ struct LzBatch {
 #ifndef LZ_EXP_HASHLOG
 #define LZ_EXP_HASHLOG 12     // experiment knob (timing only: any other value changes the output)
 #endif
-#define LZ_WAVES_FAST      13
-#define LZ_WAVES_FAST_HUF  9
+#define LZ_WAVES_FAST      16
+#define LZ_NLDS_FAST       12
+#define LZ_WAVES_FAST_HUF  16
+#define LZ_NLDS_FAST_HUF   5
 
 // NLDS of the W waves keep their hash table in LDS, the others in the wave's global-memory slot (a.tables).
 template <int PARSER, int HASHLOG, int AUX, bool HUF, int W, int WSWORDS, int NLDS = (HASHLOG > 14 ? 0 : W)>
@@ -46,6 +48,11 @@ __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
     struct Slice { u64 ring[PARSER != LZ_PARSER_PRICEFAST ? LZ_SEQ_RING : 1]; u32 ws[WSWORDS]; };
     __shared__ u32 ldsTables[NLDS ? NLDS : 1][NLDS ? LZ_TAB_BYTES(HASHLOG) / 4u : 1];
     __shared__ Slice lds[W];
+    // fast parser, mixed residency: the global-table waves need the round tag array of LzTabWide; with the Huffman
+    // stage it aliases their workspace, without it they get their own 2 KiB here
+    constexpr bool kMixedFast = PARSER == LZ_PARSER_FAST && NLDS != 0 && NLDS != W;
+    constexpr bool kOwnTags = kMixedFast && !HUF;
+    __shared__ u32 wideTags[kOwnTags ? W - NLDS : 1][kOwnTags ? (1u << LZ_WIDE_TAGLOG) / 4u : 1];
     const u32 wave = lz_uniform(threadIdx.x >> 6);               // readfirstlane: the wave index (and everything derived from it) lives in SGPRs
     Slice& my = lds[wave];
     const u64 slot = (u64)blockIdx.x * W + wave;
@@ -54,14 +61,15 @@ __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
     if constexpr (NLDS == W)      tableMem = (void*)ldsTables[wave];
     else if constexpr (NLDS == 0) tableMem = (void*)(a.tables + slot * a.tableStride);
     else tableMem = wave < (u32)NLDS ? (void*)ldsTables[wave] : (void*)(a.tables + slot * a.tableStride);   // (priceFast: u32 slots there)
+    const bool tab32 = NLDS != 0 && NLDS != W && wave >= (u32)NLDS;   // my table is in global memory, u32 slots
+    u8* const ws = (kOwnTags && tab32) ? (u8*)wideTags[kOwnTags ? wave - NLDS : 0] : (u8*)my.ws;
     for (;;) {
         lz_converge();
         const u32 b = lz_claim_index(a.counter);
         if (b >= a.nBlocks) break;
         const u32 n = (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
         const u32 c = lz_compress_block<PARSER, HASHLOG, AUX, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
-                                                                  a.level, tableMem, (u8*)my.ws, scratch, my.ring,
-                                                                  PARSER == LZ_PARSER_PRICEFAST && NLDS != W && wave >= (u32)NLDS);
+                                                                  a.level, tableMem, ws, scratch, my.ring, tab32);
         if (lz_lane() == 0) a.sizes[b] = c;
         lz_converge();
     }
@@ -71,7 +79,8 @@ __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
 template <bool HUF>
 __global__ __launch_bounds__(64 * (HUF ? LZ_WAVES_FAST_HUF : LZ_WAVES_FAST)) void lz_fast12_kernel(LzBatch a)
 {
-    lz_wave_main<LZ_PARSER_FAST, LZ_EXP_HASHLOG, 0, HUF, (HUF ? LZ_WAVES_FAST_HUF : LZ_WAVES_FAST), (HUF ? LZ_HUF_WS_WORDS : 1)>(a);
+    lz_wave_main<LZ_PARSER_FAST, LZ_EXP_HASHLOG, 0, HUF, (HUF ? LZ_WAVES_FAST_HUF : LZ_WAVES_FAST), (HUF ? LZ_HUF_WS_WORDS : 1),
+                 (HUF ? LZ_NLDS_FAST_HUF : LZ_NLDS_FAST)>(a);
 }
 
 // levels 11 / 31: fast parser, 2^18-slot table (u32 slots, 1 MiB per wave in global memory: L2 / Infinity Cache)
@@ -225,7 +234,7 @@ int launch_locked(const void* d_src, size_t nBlocks, size_t blockSize, size_t la
             a.tables = g_ctx.tables;
         }
     }
-    if (lv == 21 || lv == 41) {
+    if (lv == 10 || lv == 30 || lv == 21 || lv == 41) {
         if (!g_ctx.pfTables) LZ_HIP(hipMalloc((void**)&g_ctx.pfTables, (size_t)g_ctx.cus * LZ_WAVES_PF * LZ_PF_SLOT_BYTES));
         a.tables = g_ctx.pfTables; a.tableStride = LZ_PF_SLOT_BYTES;
     }
@@ -287,7 +296,7 @@ int LizardGPU_residentWaves(void)
 {
     pthread_mutex_lock(&g_mu);
     int rc = ctx_init_locked();
-    int w = rc ? rc : g_ctx.cus * LZ_WAVES_FAST;      // level-10 residency (13 waves per CU)
+    int w = rc ? rc : g_ctx.cus * LZ_WAVES_FAST;      // level-10 residency (16 waves per CU: 12 LDS tables + 4 in global memory)
     pthread_mutex_unlock(&g_mu);
     return w;
 }

@@ -342,7 +342,9 @@ template <int HASHLOG> LZ_DEV void lz_tab_fresh(const LzTab& t) { lz_tab_sweep<H
 // cross-lane ordering needs the full wave sync.  Table accesses are what a round costs here, so same-slot
 // lanes of a round are found through a small LDS tag array (as in lz_pricefast.h) instead of put + read-back,
 // and nothing is stored speculatively: one gather and one scatter per round.
+#ifndef LZ_WIDE_TAGLOG
 #define LZ_WIDE_TAGLOG 11
+#endif
 struct LzTabWide {
     u32* w;
     u8* tag;                                                                     // LDS, 2^LZ_WIDE_TAGLOG bytes
@@ -704,6 +706,7 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
         lz_hc_build<AUX>(src, n, hc);
     }
     else if constexpr (kWide) lz_tab_fresh<HASHLOG>(tabw);
+    else if (PARSER == LZ_PARSER_FAST && tab32) lz_tab_fresh<HASHLOG>(tabw);
     else if constexpr (PARSER == LZ_PARSER_FAST) { lz_tab_fresh<HASHLOG>(tab); st.sweepAt = 32768u; }
     else if (tab32) { LzTab32 t32; t32.w = (u32*)tableMem; for (u32 i = lane; i < (1u << HASHLOG); i += 64u) lz_tab_set(t32, i, LZ_EMPTY24); }
     else for (u32 i = lane; i < (1u << HASHLOG); i += 64u) lz_tab_set(tab, i, LZ_EMPTY24);
@@ -718,6 +721,7 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
         st.nseq = 0; st.lastLits = 0;
         if constexpr (PARSER == LZ_PARSER_HASHCHAIN) lz_parse_hashchain(src, pos, pos + part, hc, st);
         else if constexpr (kWide)                    lz_parse_fast<HASHLOG>(src, pos, pos + part, tabw, st);
+        else if (PARSER == LZ_PARSER_FAST && tab32)  lz_parse_fast<HASHLOG>(src, pos, pos + part, tabw, st);
         else if constexpr (PARSER == LZ_PARSER_FAST) lz_parse_fast<HASHLOG>(src, pos, pos + part, tab, st);
         else if (tab32) { LzTab32 t32; t32.w = (u32*)tableMem; lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, t32, ws, st); }
         else                                    lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, tab, ws, st);

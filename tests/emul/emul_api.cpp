@@ -41,7 +41,7 @@ extern "C" int emul_compress_block(const void* src, int n, void* dst, int level,
     if (!hashLog) return -1;
     if (hcLevel && (size_t)n > kHcMaxBlock) return -1;
     a.src = (const u8*)src; a.n = (u32)n; a.dst = (u8*)dst; a.level = (u32)level; a.result = 0;
-    a.tab32 = (base == 21 || base == 22) && (seed & 1u);      // priceFast: odd seeds run the u32-slot (global-memory) table layout
+    a.tab32 = (base == 21 || base == 22 || base == 10) && (seed & 1u);   // odd seeds run the u32-slot (global-memory) table layout of the mixed-residency kernels
     a.table = (u32*)aligned_alloc(64, (sizeof(u32) << hashLog) + 64);
     a.tag = (u8*)malloc(8192);
     a.scratch = (u8*)malloc(LZ_SCRATCH_BYTES);
