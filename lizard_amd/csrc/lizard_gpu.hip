@@ -1,11 +1,10 @@
 // lizard_gpu.hip — gfx950 kernels + the thin extern "C" shim the host C layer (lizard_host.c) calls.
 //
-// Launch geometry: ONE wavefront (64-thread workgroup) per Lizard API block; the grid is persistent
-// (CUs x resident-workgroups-per-CU) and pulls block indices from a device counter, so a launch over
-// 65 536 blocks keeps every CU's LDS full of match-finder tables (level 10: 16 KiB table + 4 KiB tag
-// per wave -> 8 waves per CU under the 160 KiB LDS) and tail blocks do not strand CUs.  Each wave owns
-// a stream-staging slot in a global scratch arena (L2/MALL resident: written and re-read once per
-// sub-block).  Blocks never communicate, so there is no inter-workgroup synchronisation at all.
+// Launch geometry: ONE wavefront per Lizard API block.  The grid is persistent — one workgroup of up to
+// 16 independent waves per CU (they never synchronise with each other) — and every wave pulls block indices
+// from a device counter, so tail blocks do not strand CUs.  Each wave owns a hash table (LDS slice or
+// global-memory slot, see lz_wave_main) and a scratch slot in a global arena (sequence list / stream staging,
+// written and re-read once per sub-block).  Blocks never communicate: no inter-workgroup synchronisation.
 #include <hip/hip_runtime.h>
 #include <pthread.h>
 #include <stdio.h>
@@ -26,13 +25,11 @@ struct LzBatch {
     u64 tableStride;
 };
 
-// Residency by construction.  LDS is what limits the number of blocks in flight, and the hardware hands it
-// out in 512-byte granules per WORKGROUP: thirteen independent 64-thread workgroups of 12 560 B each get
-// 12 800 B apiece, so only twelve fit in a CU's 160 KiB (the occupancy API, which divides raw sizes, says
-// thirteen).  Instead ONE workgroup per CU carries W independent waves and declares W private slices
-// of one allocation: 13 x 12 548 B = 163 124 B (level 10), 9 x 17 932 B (level 30), 3 x 53 252 B /
-// 3 x 54 540 B (levels 21 / 41) — 98.5-99.9 % of the CU's LDS.  The waves never synchronise with each other
-// (no s_barrier anywhere); each claims blocks from the device counter on its own.
+// Residency by construction.  LDS is what limits the number of tables in flight, and the hardware hands it out
+// in 512-byte granules per WORKGROUP: thirteen independent 64-thread workgroups of 12 560 B each get 12 800 B
+// apiece, so only twelve fit in a CU's 160 KiB (the occupancy API, which divides raw sizes, says thirteen).
+// Instead ONE workgroup per CU carries W waves and private slices of one allocation; NLDS of them keep their
+// hash table in LDS, the others in a global-memory slot (DESIGN.md section 4 lists the split per level).
 #ifndef LZ_EXP_HASHLOG
 #define LZ_EXP_HASHLOG 12     // experiment knob (timing only: any other value changes the output)
 #endif
