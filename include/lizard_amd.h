@@ -36,7 +36,8 @@ int Lizard_versionNumber(void);
 
 /* reference lib/lizard_compress.h:99 / lib/lizard_compress.c:596.
  * Returns bytes written into dst, 0 on failure (dst too small, level not accelerated, GPU error).
- * Never writes past dst+maxDstSize, never reads outside src[0..srcSize). */
+ * Never writes past dst+maxDstSize, never reads outside src[0..srcSize).  (maxDstSize <= 0 returns 0;
+ * the reference's room test wraps there, lizard_compress.c:238/:489, and it writes past the buffer.) */
 int Lizard_compress(const char* src, char* dst, int srcSize, int maxDstSize, int compressionLevel);
 
 /* reference lib/lizard_compress.h:135 / lib/lizard_compress.c:67 */
@@ -45,7 +46,7 @@ int Lizard_compressBound(int inputSize);
 /* reference lib/lizard_compress.h:145-147 / lib/lizard_compress.c:311,583.
  * `state` must be pointer-aligned (misaligned => 0, as the reference) and Lizard_sizeofState(level)
  * bytes; its content on entry is irrelevant (the reference re-initialises it on every call, and the
- * match-finder tables of this implementation live in LDS). */
+ * match-finder tables of this implementation live on the device). */
 int Lizard_sizeofState(int compressionLevel);
 int Lizard_compress_extState(void* state, const char* src, char* dst, int srcSize, int maxDstSize, int compressionLevel);
 
@@ -74,7 +75,9 @@ enum {
 };
 
 /* 1 if `compressionLevel` (after the reference's clamp, lib/lizard_compress.c:303-308) runs on the GPU:
- * 10, 30 (fastSmall), 11, 31 (fast, blocks <= 4 MiB), 21, 41 (priceFast, blocks < 16 MiB), 30/31/41 with huff0. */
+ * 10 (fastSmall), 11 (fast, blocks <= 4 MiB), 13..17 (hashChain, blocks <= 4 MiB), 21 (priceFast, blocks
+ * < 16 MiB) and their huff0 twins 30, 31, 34..38, 41 — the rows of Lizard_defaultParameters
+ * (lib/lizard_common.h:234-284) whose parser is fastSmall, fast, hashChain or priceFast. */
 int LizardGPU_levelSupported(int compressionLevel);
 
 /* Select the HIP device used by this process for subsequent calls (default: current device 0).
