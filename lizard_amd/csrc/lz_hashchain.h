@@ -233,17 +233,22 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 S, u32 E, const LzHc& hc, LzSt
             if (ip >= mflimit) goto tail;
             const u32 p = (u32)ip + lane;
             const bool valid = (int)p < mflimit;
-            bool hit = false;
-            if (valid) {
-                const u32 first4 = lz_ld32(src + p);
-                u32 m = p;
-                for (u32 a = 0; a < hc.searchNum; a++) {
-                    const u32 d = hc.prev[m];
-                    if (!d) break;
-                    m -= d;
-                    if (p - m > LZ_MAX_DIST_LZ4) break;
-                    if (p - m >= LZ_MIN_OFFSET && lz_ld32(src + m) == first4) { hit = true; break; }
-                }
+            // Wave-uniform loop over chain steps.  A step costs one round trip: the candidate's 4 bytes and
+            // its own link are fetched together.  Lanes above the lowest lane that already has a match stop
+            // walking — the reference never reaches their positions.
+            bool hit = false, walking = valid;
+            const u32 first4 = lz_ld32(src + (valid ? p : S));
+            u32 m = valid ? p : S;
+            u32 d = hc.prev[m];
+            for (u32 a = 0; a < hc.searchNum; a++) {
+                walking = walking && d != 0u && p - (m - d) <= LZ_MAX_DIST_LZ4;
+                if (!lz_ballot(walking)) break;
+                m = walking ? m - d : m;
+                const u32 c4 = lz_ld32(src + m);
+                d = hc.prev[m];
+                if (walking && p - m >= LZ_MIN_OFFSET && c4 == first4) { hit = true; walking = false; }
+                const u64 hm = lz_ballot(hit);
+                if (hm) walking = walking && lane < lz_ctz64(hm);
             }
             const u64 okMask = lz_ballot(hit);
             if (okMask) { ip += (int)lz_ctz64(okMask); break; }
