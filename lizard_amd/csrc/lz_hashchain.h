@@ -143,7 +143,7 @@ LZ_DEV void lz_hc_build(const u8* src, u32 n, const LzHc& hc)
 // and 8 bytes backward with lane-local loads.  Lanes whose comparison is still open after that (long
 // matches) are finished one at a time with the wave-wide helpers, skipping those that cannot reach the
 // best length any more.  "First strictly longer candidate in chain order" == maximum length, lowest lane.
-LZ_DEV u32 lz_hc_search(const u8* src, const LzHc& hc, u32 X, u32 iLow, u32 iHigh, u32 longest, bool wider, u32& ref, u32& start)
+LZ_DEV u32 lz_hc_search(const u8* src, const LzHc& hc, u32 X, u32 iLow, u32 iHigh, u32 longest, bool wider, u32& ref, u32& start, LzStreams& st)
 {
     const u32 lane = lz_lane();
     const u32 first4 = lz_ld32(src + X);
@@ -162,6 +162,7 @@ LZ_DEV u32 lz_hc_search(const u8* src, const LzHc& hc, u32 X, u32 iLow, u32 iHig
             cnt++;
         }
         left -= cnt;
+        LZ_PROF(st, 8);                                          // (instrumented build) chain walk
         const bool ok = lane < cnt && X - cand >= LZ_MIN_OFFSET && lz_ld32(src + cand) == first4;   // :73 / :146
         u32 mlt = 0, bk = 0;
         bool open = false;                                       // my comparison needs the wave-wide helpers
@@ -192,6 +193,7 @@ LZ_DEV u32 lz_hc_search(const u8* src, const LzHc& hc, u32 X, u32 iLow, u32 iHig
             }
             mlt = f + bk;
         }
+        LZ_PROF(st, 9);                                          // per-lane measurement
         // best of the lanes that are already exact: max length, lowest lane on ties
         const u32 key = (ok && !open) ? (mlt << 6) | (63u - lane) : 0u;
         const u32 top = lz_readlane(lz_wave_reduce_max(key), 63u);
@@ -210,6 +212,7 @@ LZ_DEV u32 lz_hc_search(const u8* src, const LzHc& hc, u32 X, u32 iLow, u32 iHig
             if (wider) { bj = lz_count_back(src, X, c, iLow); mj += bj; }      // :150-152
             if (mj > bestMl || (mj == bestMl && j < bestLane)) { bestMl = mj; bestLane = j; bestBack = bj; bestOpen = true; }
         }
+        LZ_PROF(st, 10);                                         // selection + wave-wide leftovers
         if (bestMl > longest) {
             const u32 c = lz_readlane(cand, bestLane);
             const u32 back = bestOpen ? bestBack : lz_readlane(bk, bestLane);
@@ -255,12 +258,12 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 S, u32 E, const LzHc& hc, LzSt
             ip += (int)lz_popc64(lz_ballot(valid));
         }
         LZ_PROF(st, 0);
-        ml = (int)lz_hc_search(src, hc, (u32)ip, (u32)ip, (u32)matchlimit, 0u, false, ref, dummy);
+        ml = (int)lz_hc_search(src, hc, (u32)ip, (u32)ip, (u32)matchlimit, 0u, false, ref, dummy, st);
         LZ_PROF(st, 1);
         start0 = ip; ref0 = ref; ml0 = ml;                                                        // :209
     search2:
         if (ip + ml < mflimit)                                                                    // :212-214
-            ml2 = (int)lz_hc_search(src, hc, (u32)(ip + ml - 2), (u32)(ip + 1), (u32)matchlimit, (u32)ml, true, ref2, start2);
+            ml2 = (int)lz_hc_search(src, hc, (u32)(ip + ml - 2), (u32)(ip + 1), (u32)matchlimit, (u32)ml, true, ref2, start2, st);
         else ml2 = ml;
         LZ_PROF(st, 2);
         if (ml2 == ml) {                                                                          // :216-219
@@ -289,7 +292,7 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 S, u32 E, const LzHc& hc, LzSt
             if (correction > 0) { start2 += (u32)correction; ref2 += (u32)correction; ml2 -= correction; }
         }
         if ((int)start2 + ml2 < mflimit)                                                          // :263-265
-            ml3 = (int)lz_hc_search(src, hc, start2 + (u32)ml2 - 3u, start2, (u32)matchlimit, (u32)ml2, true, ref3, start3);
+            ml3 = (int)lz_hc_search(src, hc, start2 + (u32)ml2 - 3u, start2, (u32)matchlimit, (u32)ml2, true, ref3, start3, st);
         else ml3 = ml2;
         LZ_PROF(st, 3);
         if (ml3 == ml2) {                                                                         // :267-275
