@@ -96,8 +96,9 @@ const char* LizardGPU_lastError(void);
  *                bound-sized slot compression cannot fail, reference lib/lizard_compress.h:104)
  *   level      : 10..49, must satisfy LizardGPU_levelSupported
  *   stream     : hipStream_t as void* (NULL = default stream). The call only enqueues work; outputs are
- *                valid after the stream is synchronised.  One call in flight per process (the per-wave
- *                scratch arena is shared).
+ *                valid after the stream is synchronised.  Launches of one process share the per-wave scratch
+ *                arena and the tables: a launch on a different stream waits on the device for the previous
+ *                one (stream-ordered, no host synchronisation).
  * Each block is what Lizard_compress_extState() produces on a zero-initialised state
  * (reference lib/lizard_compress.c:583 built with -DLIZARD_RESET_MEM). Returns 0 or -LIZARDGPU_ERR_*. */
 int LizardGPU_compressBlocks_device(const void* d_src, size_t nBlocks, size_t blockSize, size_t lastBlockSize,

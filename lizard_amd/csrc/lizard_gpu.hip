@@ -237,6 +237,9 @@ int launch_locked(const void* d_src, size_t nBlocks, size_t blockSize, size_t la
     }
     u32 grid = (u32)((nBlocks + W - 1) / W);
     if (grid > (u32)g_ctx.cus) grid = (u32)g_ctx.cus;
+    // The scratch arena, the tables and the block counter are shared by all launches of this process: a launch
+    // on another stream first waits (on the GPU) for the previous one to finish.
+    if (g_ctx.timed) LZ_HIP(hipStreamWaitEvent(stream, g_ctx.ev1, 0));
     LZ_HIP(hipMemsetAsync(g_ctx.counter, 0, 4, stream));
     LZ_HIP(hipEventRecord(g_ctx.ev0, stream));
     switch (lv) {
