@@ -37,6 +37,8 @@ struct LzBatch {
 #define LZ_NLDS_FAST       12
 #define LZ_WAVES_FAST_HUF  16
 #define LZ_NLDS_FAST_HUF   5
+#define LZ_WAVES_FASTLDS      13             // all tables in LDS (blocks above 4 MiB)
+#define LZ_WAVES_FASTLDS_HUF  9
 
 // NLDS of the W waves keep their hash table in LDS, the others in the wave's global-memory slot (a.tables).
 template <int PARSER, int HASHLOG, int AUX, bool HUF, int W, int WSWORDS, int NLDS = (HASHLOG > 14 ? 0 : W)>
@@ -72,12 +74,20 @@ __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
     }
 }
 
-// levels 10 / 30: fastSmall parser, 2^12-slot table (24-bit slots, 12 KiB) + sequence ring (+ Huffman workspace)
-template <bool HUF>
-__global__ __launch_bounds__(64 * (HUF ? LZ_WAVES_FAST_HUF : LZ_WAVES_FAST)) void lz_fast12_kernel(LzBatch a)
+// levels 10 / 30: fastSmall parser, 2^12-slot table + sequence ring (+ Huffman workspace).  MIXED: 16 waves, of which
+// 12 (5 with the Huffman workspaces) keep the 24-bit-slot table (12 KiB) in LDS and the others a u32-slot table
+// in global memory — full 22-bit positions there, hence blocks up to 4 MiB; larger blocks run the all-LDS form
+// (13 / 9 waves), whose 17-bit relative positions have no size limit.
+template <bool HUF, bool MIXED>
+__global__ __launch_bounds__(64 * (MIXED ? (HUF ? LZ_WAVES_FAST_HUF : LZ_WAVES_FAST) : (HUF ? LZ_WAVES_FASTLDS_HUF : LZ_WAVES_FASTLDS)))
+void lz_fast12_kernel(LzBatch a)
 {
-    lz_wave_main<LZ_PARSER_FAST, LZ_EXP_HASHLOG, 0, HUF, (HUF ? LZ_WAVES_FAST_HUF : LZ_WAVES_FAST), (HUF ? LZ_HUF_WS_WORDS : 1),
-                 (HUF ? LZ_NLDS_FAST_HUF : LZ_NLDS_FAST)>(a);
+    if constexpr (MIXED)
+        lz_wave_main<LZ_PARSER_FAST, LZ_EXP_HASHLOG, 0, HUF, (HUF ? LZ_WAVES_FAST_HUF : LZ_WAVES_FAST), (HUF ? LZ_HUF_WS_WORDS : 1),
+                     (HUF ? LZ_NLDS_FAST_HUF : LZ_NLDS_FAST)>(a);
+    else
+        lz_wave_main<LZ_PARSER_FAST, LZ_EXP_HASHLOG, 0, HUF, (HUF ? LZ_WAVES_FASTLDS_HUF : LZ_WAVES_FASTLDS), (HUF ? LZ_HUF_WS_WORDS : 1),
+                     (HUF ? LZ_WAVES_FASTLDS_HUF : LZ_WAVES_FASTLDS)>(a);
 }
 
 // levels 11 / 31: fast parser, 2^18-slot table (u32 slots, 1 MiB per wave in global memory: L2 / Infinity Cache)
@@ -204,7 +214,8 @@ int launch_locked(const void* d_src, size_t nBlocks, size_t blockSize, size_t la
     a.level = (u32)lv;
     // one workgroup of W waves per CU; small batches launch only as many workgroups as they have blocks for
     const bool hcLevel = (lv >= 13 && lv <= 17) || (lv >= 34 && lv <= 38);
-    const u32 W = lv == 10 ? LZ_WAVES_FAST : lv == 30 ? LZ_WAVES_FAST_HUF : (lv == 11 || lv == 31) ? LZ_WAVES_FAST18 : hcLevel ? LZ_WAVES_HC : LZ_WAVES_PF;
+    const bool fastMixed = blockSize <= (4u << 20);                         // global-table waves hold 22-bit positions
+    const u32 W = lv == 10 ? (fastMixed ? LZ_WAVES_FAST : LZ_WAVES_FASTLDS) : lv == 30 ? (fastMixed ? LZ_WAVES_FAST_HUF : LZ_WAVES_FASTLDS_HUF) : (lv == 11 || lv == 31) ? LZ_WAVES_FAST18 : hcLevel ? LZ_WAVES_HC : LZ_WAVES_PF;
     a.tableStride = LZ_TABWIDE_BYTES(18);
     if (hcLevel) {
         if (blockSize > (4u << 20)) {
@@ -243,8 +254,12 @@ int launch_locked(const void* d_src, size_t nBlocks, size_t blockSize, size_t la
     LZ_HIP(hipMemsetAsync(g_ctx.counter, 0, 4, stream));
     LZ_HIP(hipEventRecord(g_ctx.ev0, stream));
     switch (lv) {
-    case 10: hipLaunchKernelGGL(lz_fast12_kernel<false>, dim3(grid), dim3(64 * LZ_WAVES_FAST), 0, stream, a); break;
-    case 30: hipLaunchKernelGGL(lz_fast12_kernel<true>, dim3(grid), dim3(64 * LZ_WAVES_FAST_HUF), 0, stream, a); break;
+    case 10: if (fastMixed) hipLaunchKernelGGL((lz_fast12_kernel<false, true>), dim3(grid), dim3(64 * LZ_WAVES_FAST), 0, stream, a);
+             else           hipLaunchKernelGGL((lz_fast12_kernel<false, false>), dim3(grid), dim3(64 * LZ_WAVES_FASTLDS), 0, stream, a);
+             break;
+    case 30: if (fastMixed) hipLaunchKernelGGL((lz_fast12_kernel<true, true>), dim3(grid), dim3(64 * LZ_WAVES_FAST_HUF), 0, stream, a);
+             else           hipLaunchKernelGGL((lz_fast12_kernel<true, false>), dim3(grid), dim3(64 * LZ_WAVES_FASTLDS_HUF), 0, stream, a);
+             break;
     case 11: hipLaunchKernelGGL(lz_fast18_kernel<false>, dim3(grid), dim3(64 * LZ_WAVES_FAST18), 0, stream, a); break;
     case 31: hipLaunchKernelGGL(lz_fast18_kernel<true>, dim3(grid), dim3(64 * LZ_WAVES_FAST18), 0, stream, a); break;
     case 13: case 14: case 15: hipLaunchKernelGGL((lz_hashchain_kernel<false, 5>), dim3(grid), dim3(64 * LZ_WAVES_HC), 0, stream, a); break;

@@ -66,6 +66,18 @@ def test_long_range_corpus(L):
             assert r == g["size"] and util.sha(out) == g["sha256"], (name, level)
 
 
+def test_blocks_above_4mib(L):
+    """Levels 10/30 switch to the all-LDS kernel above 4 MiB (the global-table waves hold 22-bit positions);
+    21/41 go up to 16 MiB; 11/31 and hashChain refuse such blocks loudly (return 0)."""
+    data = util.datagen((5 << 20) + 123, 0.5, 0.0, 31) + bytes(300000) + util.datagen(1 << 20, 0.2, 0.0, 32)
+    for level in (10, 30, 21):
+        out, r = gpu_compress(L, data, level)
+        assert out == util.oracle_compress(data, level), level
+    for level in (11, 13):
+        out, r = gpu_compress(L, data, level)
+        assert r == 0, level
+
+
 def test_frame_style_capacity(L):
     """maxDstSize = srcSize-1 (reference lib/lizard_frame.c:461): identical bytes when it fits, 0 when not."""
     for level in [l for l in (10, 21, 30) if L.LizardGPU_levelSupported(l)]:
