@@ -9,7 +9,7 @@ pass () { name=$1; shift
 import csv, sys, collections
 agg = collections.defaultdict(float)
 for r in csv.DictReader(open(sys.argv[1])):
-    if 'lz_fast' in r.get('Kernel_Name','') or 'lz_price' in r.get('Kernel_Name',''): agg[r['Counter_Name']] += float(r['Counter_Value'])
+    if any(k in r.get('Kernel_Name','') for k in ('lz_fast', 'lz_price', 'lz_hashchain')): agg[r['Counter_Name']] += float(r['Counter_Value'])
 print(sys.argv[2], dict(agg))
 PY
 }
