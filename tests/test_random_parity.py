@@ -1,0 +1,81 @@
+"""Randomised parity: inputs stitched together from segment kinds that stress different rules of the
+reference (datagen at random compressibility, noise, constant runs, short periods, copies of earlier
+slices at distances around the 64 KiB window edge, text) at random ragged sizes, one block per call, every
+level — against the oracle, which tests/test_oracle.py pins to the compiled reference.
+
+CPU: a few small cases through the SIMT emulator.  GPU (-m gpu): a few hundred through the C ABI."""
+import random
+
+import pytest
+
+import util
+from test_emulator import emul_compress
+
+LEVELS = [10, 11, 13, 14, 15, 16, 17, 21, 30, 31, 34, 35, 36, 37, 38, 41]
+
+
+def make_case(rng, max_size):
+    target = rng.choice([rng.randrange(1, 64), rng.randrange(64, 5000), rng.randrange(5000, max_size), max_size,
+                         131072 + rng.randrange(-40, 40)])
+    target = max(1, min(target, max_size))
+    out = bytearray()
+    while len(out) < target:
+        kind = rng.randrange(7)
+        n = rng.choice([rng.randrange(1, 40), rng.randrange(40, 3000), rng.randrange(3000, 70000)])
+        if kind == 0:
+            seg = util.datagen(n, rng.choice([0.0, 0.1, 0.3, 0.5, 0.7, 0.9, 1.0]), 0.0, rng.randrange(1 << 30))
+        elif kind == 1:
+            seg = rng.randbytes(n)
+        elif kind == 2:
+            seg = bytes([rng.randrange(256)]) * n
+        elif kind == 3:
+            per = rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 63, 64, 65, 255, 300])
+            pat = rng.randbytes(per)
+            seg = (pat * (n // per + 1))[:n]
+        elif kind == 4 and len(out) > 16:                      # copy of an earlier slice: long-distance matches
+            dist = rng.choice([8, 9, 15, 16, 100, 4096, 65527, 65534, 65535, 65536, 65537, 70000, len(out)])
+            dist = min(dist, len(out))
+            start = len(out) - dist
+            seg = bytes(out[start:start + min(n, dist)])
+        elif kind == 5:
+            words = [b"the ", b"quick ", b"brown ", b"fox ", b"jumps ", b"over ", b"lazy ", b"dog ", b"lizard ", b"\n"]
+            seg = b"".join(rng.choice(words) for _ in range(n // 5 + 1))[:n]
+        else:
+            seg = bytes(rng.choice(b"ab") for _ in range(min(n, 4000)))
+        out += seg
+    return bytes(out[:target])
+
+
+def test_emulated_random_cases():
+    rng = random.Random(20240924)
+    for trial in range(48):
+        data = make_case(rng, 140000)
+        level = LEVELS[trial % len(LEVELS)] if trial < len(LEVELS) else rng.choice(LEVELS)
+        assert emul_compress(data, level, seed=trial) == util.oracle_compress(data, level), (trial, level, len(data))
+
+
+@pytest.mark.gpu
+def test_gpu_random_cases():
+    from lizard_amd import _lib
+    L = _lib.lib()
+    rng = random.Random(777)
+    for trial in range(1000):
+        data = make_case(rng, 400000)
+        level = rng.choice(LEVELS)
+        out, r = util.compress_with(L.Lizard_compress, data, level)
+        assert out == util.oracle_compress(data, level), (trial, level, len(data))
+
+
+@pytest.mark.gpu
+def test_gpu_random_batches():
+    """Same generator through the batch entry: many blocks per launch, so every kind of wave of the
+    mixed-residency kernels (LDS tables, global-memory tables) takes part."""
+    from lizard_amd import api
+    rng = random.Random(4242)
+    for trial in range(32):
+        level = LEVELS[(3 * trial) % len(LEVELS)]
+        bs = rng.choice([4096, 30000, 65536, 131072, 262144])
+        data = b"".join(make_case(rng, 300000) for _ in range(24))
+        outs = api.compress_blocks(data, bs, level)
+        for i, o in enumerate(outs):
+            assert o == util.oracle_compress(data[i * bs:(i + 1) * bs], level), (trial, level, bs, i)
