@@ -62,6 +62,13 @@ int Lizard_compress_extState_MinLevel(void* state, const char* source, char* des
 Lizard_stream_t* Lizard_resetStream_MinLevel(Lizard_stream_t* streamPtr);
 Lizard_stream_t* Lizard_createStream_MinLevel(void);
 
+/* reference lib/lizard_compress.h:178,198,188 / lib/lizard_compress.c:426,454,550 — linked blocks and
+ * dictionaries.  Present so that reference programs link unchanged; NOT implemented on this path (a serial
+ * chain between blocks): each returns 0, the reference's failure value, after one message on stderr. */
+int Lizard_loadDict(Lizard_stream_t* streamPtr, const char* dictionary, int dictSize);
+int Lizard_saveDict(Lizard_stream_t* streamPtr, char* safeBuffer, int dictSize);
+int Lizard_compress_continue(Lizard_stream_t* streamPtr, const char* src, char* dst, int srcSize, int maxDstSize);
+
 /* ======================= Part 2: batch extension (ours) ======================= */
 
 /* Error codes returned (negated) by the LizardGPU_* entry points. */

@@ -81,3 +81,24 @@ int Lizard_compress_MinLevel(const char* source, char* dest, int inputSize, int 
 { return Lizard_compress(source, dest, inputSize, maxOutputSize, LIZARD_MIN_CLEVEL); }
 Lizard_stream_t* Lizard_createStream_MinLevel(void) { return Lizard_createStream(LIZARD_MIN_CLEVEL); }
 Lizard_stream_t* Lizard_resetStream_MinLevel(Lizard_stream_t* s) { return Lizard_resetStream(s, LIZARD_MIN_CLEVEL); }
+
+/* Linked blocks and dictionaries (reference lib/lizard_compress.h:178,188,198 / lib/lizard_compress.c:426,454,550): every
+ * block's window reaches into the previous one, a serial chain that has no place on this path.  The symbols
+ * exist so that programs written against the reference (lizard_frame.c's linked mode, lizardio.c) link
+ * unchanged; they fail the way the reference reports failure — 0 — after saying why, once, on stderr.  A frame
+ * written in linked mode through them stores its blocks raw (lizard_frame.c:463-467). */
+static void refuse_linked(const char* what)
+{
+    static int warned = 0;
+    if (!warned) {
+        warned = 1;
+        fprintf(stderr, "liblizard_amd: %s: linked blocks / dictionaries are serial and not part of the GPU path "
+                        "(use independent blocks, e.g. lizard -BI) — returning 0\n", what);
+    }
+}
+int Lizard_loadDict(Lizard_stream_t* streamPtr, const char* dictionary, int dictSize)
+{ (void)streamPtr; (void)dictionary; (void)dictSize; refuse_linked("Lizard_loadDict"); return 0; }
+int Lizard_saveDict(Lizard_stream_t* streamPtr, char* safeBuffer, int dictSize)
+{ (void)streamPtr; (void)safeBuffer; (void)dictSize; refuse_linked("Lizard_saveDict"); return 0; }
+int Lizard_compress_continue(Lizard_stream_t* streamPtr, const char* src, char* dst, int srcSize, int maxDstSize)
+{ (void)streamPtr; (void)src; (void)dst; (void)srcSize; (void)maxDstSize; refuse_linked("Lizard_compress_continue"); return 0; }

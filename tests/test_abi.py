@@ -60,3 +60,63 @@ def test_no_gpu_means_loud_failure(lib):
     assert lib.Lizard_compress(b"a" * 100, dst, 100, 1000, 10) == 0   # reference: 0 == failure
     lib.LizardGPU_lastError.restype = ctypes.c_char_p
     assert lib.LizardGPU_lastError() != b""
+
+
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "programs")), reason="reference checkout not present (GPU box)")
+def test_reference_cli_links_against_library(lib, tmp_path):
+    """INTEGRATION.md section 1, literally: the reference's own CLI objects (bench, lizardio, lizardcli, datagen) plus
+    its decoder / frame layer / xxhash, linked against liblizard_amd.so INSTEAD of lizard_compress.o and the
+    entropy encoders.  Everything is compiled into a temporary directory from the sources where they lie.
+    Without a GPU the library must fail loudly and the frame layer then stores the blocks raw: the file still
+    round-trips through the reference decoder."""
+    import torch
+    srcs = ["programs/bench.c", "programs/lizardio.c", "programs/lizardcli.c", "programs/datagen.c",
+            "lib/lizard_decompress.c", "lib/lizard_frame.c", "lib/xxhash/xxhash.c", "lib/entropy/entropy_common.c",
+            "lib/entropy/fse_decompress.c", "lib/entropy/huf_decompress.c"]
+    objs = []
+    for f in srcs:
+        o = str(tmp_path / (os.path.basename(f)[:-2] + ".o"))
+        subprocess.check_call(["gcc", "-O1", "-w", "-I", REF + "/lib", "-I", REF + "/lib/xxhash", "-I", REF + "/programs",
+                               "-DXXH_NAMESPACE=Lizard_", "-c", os.path.join(REF, f), "-o", o])
+        objs.append(o)
+    exe = str(tmp_path / "lizard_on_gpu_lib")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-o", exe] + objs + ["-L", libdir, "-llizard_amd", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe, "--version"], capture_output=True, text=True)
+    assert "Lizard command line interface" in out.stdout + out.stderr
+    if torch.cuda.is_available():
+        return
+    data = util.datagen(300000, 0.5, 0.0, 4)
+    (tmp_path / "in.bin").write_bytes(data)
+    r = subprocess.run([exe, "-10", "-f", str(tmp_path / "in.bin"), str(tmp_path / "out.liz")], capture_output=True, text=True)
+    assert r.returncode == 0 and "no CPU fallback" in r.stderr          # loud, and the frame layer stored raw blocks
+    r = subprocess.run([exe, "-d", "-f", str(tmp_path / "out.liz"), str(tmp_path / "back.bin")], capture_output=True, text=True)
+    assert r.returncode == 0 and (tmp_path / "back.bin").read_bytes() == data
+
+
+@pytest.mark.gpu
+def test_reference_cli_runs_on_the_gpu_library(tmp_path):
+    """The reference's own CLI, built against liblizard_amd.so by oracle/Makefile (oracle/_ref/lizard_cli_amd,
+    travels to the GPU box as a binary): compress a file with it, decode it with the reference decoder inside the
+    same binary, and check that the frame is byte for byte what the oracle composition predicts for the header
+    the CLI chose — i.e. every block really went through the GPU path and came out bit-exact."""
+    exe = os.path.join(util.ROOT, "oracle", "_ref", "lizard_cli_amd")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/lizard_cli_amd not built")
+    data = util.datagen((9 << 20) + 12345, 0.5, 0.0, 17)
+    (tmp_path / "in.bin").write_bytes(data)
+    for level, extra in ((10, []), (30, ["-B1"]), (21, ["-B2"])):
+        liz, back = tmp_path / f"out{level}.liz", tmp_path / f"back{level}.bin"
+        r = subprocess.run([exe, f"-{level}", "-f"] + extra + [str(tmp_path / "in.bin"), str(liz)], capture_output=True, text=True)
+        assert r.returncode == 0 and "no CPU fallback" not in r.stderr, r.stderr
+        frame = liz.read_bytes()
+        assert len(frame) < 0.75 * len(data)                         # compressed, not stored raw
+        flg, bd = frame[4], frame[5]
+        assert (flg >> 5) & 1 == 1                                   # independent blocks (CLI default)
+        want = util.compose_frame(data, level, (bd >> 4) & 7, (flg >> 2) & 1, (flg >> 3) & 1, util.oracle_compress)
+        assert frame == want, level
+        r = subprocess.run([exe, "-d", "-f", str(liz), str(back)], capture_output=True, text=True)
+        assert r.returncode == 0 and back.read_bytes() == data
