@@ -34,8 +34,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-KERNEL_OF_LEVEL = {10: "lz_fast12_kernel<false>", 30: "lz_fast12_kernel<true>", 11: "lz_fast18_kernel<false>",
-                   31: "lz_fast18_kernel<true>", 21: "lz_pricefast14_kernel<false>", 41: "lz_pricefast14_kernel<true>"}
+KERNEL_OF_LEVEL = {10: "lz_fast12_kernel<false, true>", 30: "lz_fast12_kernel<true, true>", 11: "lz_fast18_kernel<false>",
+                   31: "lz_fast18_kernel<true>", 21: "lz_pricefast14_kernel<false>", 41: "lz_pricefast14_kernel<true>",
+                   22: "lz_pricefast18_kernel<false>", 42: "lz_pricefast18_kernel<true>"}
 for _l in range(13, 18):       # hashChain rows: searchLength 5 for 13-15 / 34-36, 4 for 16-17 / 37-38
     KERNEL_OF_LEVEL[_l] = "lz_hashchain_kernel<false, %d>" % (5 if _l <= 15 else 4)
     KERNEL_OF_LEVEL[_l + 21] = "lz_hashchain_kernel<true, %d>" % (5 if _l <= 15 else 4)

@@ -82,8 +82,8 @@ enum {
 };
 
 /* 1 if `compressionLevel` (after the reference's clamp, lib/lizard_compress.c:303-308) runs on the GPU:
- * 10 (fastSmall), 11 (fast, blocks <= 4 MiB), 13..17 (hashChain, blocks <= 4 MiB), 21 (priceFast, blocks
- * < 16 MiB) and their huff0 twins 30, 31, 34..38, 41 — the rows of Lizard_defaultParameters
+ * 10 (fastSmall), 11 (fast, blocks <= 4 MiB), 13..17 (hashChain, blocks <= 4 MiB), 21, 22 (priceFast, blocks
+ * < 16 MiB) and their huff0 twins 30, 31, 34..38, 41, 42 — every row of Lizard_defaultParameters
  * (lib/lizard_common.h:234-284) whose parser is fastSmall, fast, hashChain or priceFast. */
 int LizardGPU_levelSupported(int compressionLevel);
 

@@ -60,7 +60,7 @@ __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
     if constexpr (NLDS == W)      tableMem = (void*)ldsTables[wave];
     else if constexpr (NLDS == 0) tableMem = (void*)(a.tables + slot * a.tableStride);
     else tableMem = wave < (u32)NLDS ? (void*)ldsTables[wave] : (void*)(a.tables + slot * a.tableStride);   // (priceFast: u32 slots there)
-    const bool tab32 = NLDS != 0 && NLDS != W && wave >= (u32)NLDS;   // my table is in global memory, u32 slots
+    const bool tab32 = NLDS != W && wave >= (u32)NLDS;               // my table is in global memory, u32 slots
     u8* const ws = (kOwnTags && tab32) ? (u8*)wideTags[kOwnTags ? wave - NLDS : 0] : (u8*)my.ws;
     for (;;) {
         lz_converge();
@@ -119,6 +119,13 @@ template <bool HUF>
 __global__ __launch_bounds__(64 * LZ_WAVES_PF) void lz_pricefast14_kernel(LzBatch a)
 {
     lz_wave_main<LZ_PARSER_PRICEFAST, 14, LZ_PF_TAGLOG, HUF, LZ_WAVES_PF, (HUF ? LZ_HUF_WS_WORDS : (1u << LZ_PF_TAGLOG) / 4u), (HUF ? 1 : 2)>(a);
+}
+
+// levels 22 / 42: priceFast + LIZv1 with a 2^18-slot table: 1 MiB of u32 slots per wave, all in global memory
+template <bool HUF>
+__global__ __launch_bounds__(64 * LZ_WAVES_PF) void lz_pricefast18_kernel(LzBatch a)
+{
+    lz_wave_main<LZ_PARSER_PRICEFAST, 18, LZ_PF_TAGLOG, HUF, LZ_WAVES_PF, (HUF ? LZ_HUF_WS_WORDS : (1u << LZ_PF_TAGLOG) / 4u), 0>(a);
 }
 
 // synthetic input: one thread per block, block b = RDG_genBuffer(blockSize, P, seed0 + b)
@@ -199,8 +206,8 @@ int launch_locked(const void* d_src, size_t nBlocks, size_t blockSize, size_t la
     if (!d_src || !d_dst || !d_sizes || nBlocks == 0 || nBlocks > 0xFFFFFFFFu) return -LIZARDGPU_ERR_ARG;
     if (blockSize == 0 || blockSize > LIZARD_MAX_INPUT_SIZE || lastBlockSize == 0 || lastBlockSize > blockSize) return -LIZARDGPU_ERR_ARG;
     if (dstStride < (size_t)LIZARD_COMPRESSBOUND((int)blockSize)) return -LIZARDGPU_ERR_ARG;
-    if ((level == 21 || level == 41) && blockSize >= (1u << 24) - 1u) {      // 24-bit table positions (lz_pricefast.h)
-        snprintf(g_ctx.err, sizeof g_ctx.err, "levels 21/41: blocks of 16 MiB or more are not supported on the GPU path");
+    if ((level == 21 || level == 41 || level == 22 || level == 42) && blockSize >= (1u << 24) - 1u) {      // 24-bit table positions (lz_pricefast.h)
+        snprintf(g_ctx.err, sizeof g_ctx.err, "levels 21/22/41/42: blocks of 16 MiB or more are not supported on the GPU path");
         return -LIZARDGPU_ERR_ARG;
     }
     int rc = ctx_init_locked();
@@ -231,6 +238,10 @@ int launch_locked(const void* d_src, size_t nBlocks, size_t blockSize, size_t la
             g_ctx.hcMaxBlock = cap;
         }
         a.tables = g_ctx.hcSlots; a.tableStride = LZ_HC_SLOT_BYTES(g_ctx.hcMaxBlock);
+    }
+    if (lv == 22 || lv == 42) {                                  // same per-wave footprint as levels 11/31
+        if (!g_ctx.tables) LZ_HIP(hipMalloc((void**)&g_ctx.tables, (size_t)g_ctx.cus * LZ_WAVES_FAST18 * LZ_TABWIDE_BYTES(18)));
+        a.tables = g_ctx.tables;
     }
     if (lv == 11 || lv == 31) {
         if (blockSize > (4u << 20)) {
@@ -266,6 +277,8 @@ int launch_locked(const void* d_src, size_t nBlocks, size_t blockSize, size_t la
     case 16: case 17:          hipLaunchKernelGGL((lz_hashchain_kernel<false, 4>), dim3(grid), dim3(64 * LZ_WAVES_HC), 0, stream, a); break;
     case 34: case 35: case 36: hipLaunchKernelGGL((lz_hashchain_kernel<true, 5>), dim3(grid), dim3(64 * LZ_WAVES_HC), 0, stream, a); break;
     case 37: case 38:          hipLaunchKernelGGL((lz_hashchain_kernel<true, 4>), dim3(grid), dim3(64 * LZ_WAVES_HC), 0, stream, a); break;
+    case 22: hipLaunchKernelGGL(lz_pricefast18_kernel<false>, dim3(grid), dim3(64 * LZ_WAVES_PF), 0, stream, a); break;
+    case 42: hipLaunchKernelGGL(lz_pricefast18_kernel<true>, dim3(grid), dim3(64 * LZ_WAVES_PF), 0, stream, a); break;
     case 21: hipLaunchKernelGGL(lz_pricefast14_kernel<false>, dim3(grid), dim3(64 * LZ_WAVES_PF), 0, stream, a); break;
     default: hipLaunchKernelGGL(lz_pricefast14_kernel<true>, dim3(grid), dim3(64 * LZ_WAVES_PF), 0, stream, a); break;
     }
@@ -293,7 +306,7 @@ int LizardGPU_levelSupported(int level)
 {
     if (level > LIZARD_MAX_CLEVEL) level = LIZARD_MAX_CLEVEL;        // reference lizard_compress.c:303-308
     if (level < LIZARD_MIN_CLEVEL) level = LIZARD_DEFAULT_CLEVEL;
-    return level == 10 || level == 30 || level == 11 || level == 31 || level == 21 || level == 41
+    return level == 10 || level == 30 || level == 11 || level == 31 || level == 21 || level == 41 || level == 22 || level == 42
         || (level >= 13 && level <= 17) || (level >= 34 && level <= 38);
 }
 
