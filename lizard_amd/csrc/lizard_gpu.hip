@@ -30,9 +30,6 @@ struct LzBatch {
 // apiece, so only twelve fit in a CU's 160 KiB (the occupancy API, which divides raw sizes, says thirteen).
 // Instead ONE workgroup per CU carries W waves and private slices of one allocation; NLDS of them keep their
 // hash table in LDS, the others in a global-memory slot (DESIGN.md section 4 lists the split per level).
-#ifndef LZ_EXP_HASHLOG
-#define LZ_EXP_HASHLOG 12     // experiment knob (timing only: any other value changes the output)
-#endif
 #define LZ_WAVES_FAST      16
 #define LZ_NLDS_FAST       12
 #define LZ_WAVES_FAST_HUF  16
@@ -83,10 +80,10 @@ __global__ __launch_bounds__(64 * (MIXED ? (HUF ? LZ_WAVES_FAST_HUF : LZ_WAVES_F
 void lz_fast12_kernel(LzBatch a)
 {
     if constexpr (MIXED)
-        lz_wave_main<LZ_PARSER_FAST, LZ_EXP_HASHLOG, 0, HUF, (HUF ? LZ_WAVES_FAST_HUF : LZ_WAVES_FAST), (HUF ? LZ_HUF_WS_WORDS : 1),
+        lz_wave_main<LZ_PARSER_FAST, 12, 0, HUF, (HUF ? LZ_WAVES_FAST_HUF : LZ_WAVES_FAST), (HUF ? LZ_HUF_WS_WORDS : 1),
                      (HUF ? LZ_NLDS_FAST_HUF : LZ_NLDS_FAST)>(a);
     else
-        lz_wave_main<LZ_PARSER_FAST, LZ_EXP_HASHLOG, 0, HUF, (HUF ? LZ_WAVES_FASTLDS_HUF : LZ_WAVES_FASTLDS), (HUF ? LZ_HUF_WS_WORDS : 1),
+        lz_wave_main<LZ_PARSER_FAST, 12, 0, HUF, (HUF ? LZ_WAVES_FASTLDS_HUF : LZ_WAVES_FASTLDS), (HUF ? LZ_HUF_WS_WORDS : 1),
                      (HUF ? LZ_WAVES_FASTLDS_HUF : LZ_WAVES_FASTLDS)>(a);
 }
 
