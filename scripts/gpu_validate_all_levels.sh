@@ -26,7 +26,7 @@ pmc L10_write WRITE_SIZE | tee -a $O/pmc_traffic.txt
 pmc L13_fetch FETCH_SIZE --level 13 --blocks 8192 | tee -a $O/pmc_traffic.txt
 pmc L13_write WRITE_SIZE --level 13 --blocks 8192 | tee -a $O/pmc_traffic.txt
 cd $R
-for cfg in "30 16384" "21 16384" "41 16384" "11 16384" "31 16384" "13 8192" "15 8192" "16 8192" "17 8192" "35 8192"; do
+for cfg in "30 16384" "21 16384" "41 16384" "22 16384" "42 16384" "11 16384" "31 16384" "13 8192" "15 8192" "16 8192" "17 8192" "35 8192"; do
   set -- $cfg
   timeout 300 python bench.py --level $1 --blocks $2 --cpu-seconds 4 --cpu-blocks 64 > $O/bench_L$1_$2.json 2>/dev/null; tail -1 $O/bench_L$1_$2.json | cut -c1-400
 done

@@ -137,6 +137,28 @@ def test_known_answers_p50_64m_device_path(L, key):
     assert torch.equal(dst.view(-1, stride)[sel], dst2.view(-1, stride)[sel])
 
 
+def test_hashchain_epoch_wrap_on_device(L):
+    """The hashChain head tables are never cleared between blocks: their slots carry a 10-bit epoch and a table is
+    re-zeroed after 1023 blocks (lz_hc_begin).  One launch over enough small blocks makes every resident wave go
+    through the wrap at least once; a sample of blocks before, around and after it must still be bit-exact."""
+    import torch
+    from lizard_amd import api
+    bs = 192
+    nb = int(L.LizardGPU_residentWaves()) * 1150
+    rnd = np.random.RandomState(5)
+    words = rnd.randint(0, 256, size=(64, 24), dtype=np.uint8)           # 64 phrases of 24 bytes: lots of matches per block
+    host = words[rnd.randint(0, 64, size=nb * (bs // 24))].reshape(-1)[:nb * bs].copy()
+    src = torch.from_numpy(host).cuda()
+    for level in (13, 37):
+        dst, sizes, stride = api.compress_blocks_device(src, bs, level)
+        torch.cuda.synchronize()
+        sz = sizes.cpu().numpy()
+        out = dst.view(-1, stride)
+        for b in list(range(0, nb, nb // 400)) + [nb - 1]:
+            want = util.oracle_compress(host[b * bs:(b + 1) * bs].tobytes(), level)
+            assert out[b, :int(sz[b])].cpu().numpy().tobytes() == want, (level, b)
+
+
 def test_roundtrip_with_reference_decoder(L):
     """Full-size property: what the GPU writes decodes with the unmodified reference decoder."""
     ref = util.reference()
