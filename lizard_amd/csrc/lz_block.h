@@ -6,24 +6,27 @@
 //                                        lib/lizard_parser_fast.h:41-196)          levels 10/30, 11/31
 //   * fastLZ4 token encoder            (reference lib/lizard_compress_lz4.h:3-86)
 //   * sub-block container              (reference lib/lizard_compress.c:141-250, 472-547)
+//   * lz_compress_block: one API block through any of the parsers (this file, lz_pricefast.h, lz_hashchain.h)
+//     and, for levels >= 30, the huff0 stage (lz_huf.h)
 //
 // How the serial parse is mapped onto a 64-lane wave (this is a re-design, not a translation):
 //   The reference walks one position at a time: hash, table get, table put, test candidate.  Between
 //   two accepted matches the positions it will visit are known in advance (the skip schedule of
 //   fast.h:75-82 restarts after every match), so ONE ROUND evaluates the next 64 visits at once:
-//     lane l -> visit v0+l -> position p, 8-byte load, hash5, LDS table read (old value).
-//   Two visits of one round can hit the same table slot; the reference would have shown the later
-//   one the earlier one's position.  A 1-byte-per-slot LDS tag array detects such rounds (every
-//   lane stores its lane id at tag[h] and reads it back); only then a short loop over the clashing
-//   hash values rebuilds, per lane, the mask of same-hash lanes, from which the in-order predecessor
-//   (and later the in-order LAST writer) follow with clz/ctz on ballot masks.
+//     lane l -> visit v0+l -> position p, 8 source bytes (loaded one round ahead), hash5, table slot.
+//   Two visits of one round can hit the same table slot; the reference would have shown the later one the
+//   earlier one's position.  Such rounds are detected without extra memory when the table is in LDS (every
+//   lane stores its entry speculatively and reads the slot back: LzTab), through a small LDS tag array when
+//   the table is in global memory (LzTabWide: nothing is stored before the winner is known); only then a
+//   short loop over the clashing hash values rebuilds, per lane, the mask of same-slot lanes, from which the
+//   in-order predecessor (and later the in-order LAST writer) follow with clz/ctz on ballot masks.
 //   Each lane then applies the reference's accept test to its candidate; the first accepting lane
 //   (ctz of the ballot) is the match the reference would have taken; lanes up to and including it
 //   commit their table puts, later lanes are discarded (the reference never reached them).
-//   Match extension (forward/backward) and the sequence encoder are wave-parallel byte operations.
-//   The reference's post-match probe of `ip` (fast.h:143-165) is folded into the next round as
-//   lane 0 ("special" lane), because with anchor == ip it is exactly a search visit that cannot
-//   extend backwards.
+//   The parser only appends (literal run, match length, offset) to a sequence list; tokens and literals are
+//   written afterwards by a wave-parallel pass (lz_encode_lz4), straight into dst when there is no Huffman stage.
+//   The reference's post-match steps (fast.h:143-165: put(ip-2), probe of ip) are slots 0 and 1 of the next
+//   run's first round: with anchor == ip the probe is exactly a search visit that cannot extend backwards.
 //
 // All cross-lane traffic goes through lz_wave.h.  Variables documented "uniform" hold the same value
 // in every lane (they are derived from ballots/readlanes and live in SGPRs).
