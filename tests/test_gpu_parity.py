@@ -159,6 +159,30 @@ def test_hashchain_epoch_wrap_on_device(L):
             assert out[b, :int(sz[b])].cpu().numpy().tobytes() == want, (level, b)
 
 
+def test_launches_on_two_streams_are_ordered(L):
+    """The scratch arena, the tables and the block counter are shared by all launches of a process: a launch on
+    another stream must wait (on the device) for the previous one.  Two streams, alternating, no host sync."""
+    import torch
+    from lizard_amd import api
+    bs, nb = 65536, 3000
+    a = torch.from_numpy(np.frombuffer(util.datagen(bs * nb, 0.5, 0.0, 91), dtype=np.uint8).copy()).cuda()
+    b = torch.from_numpy(np.frombuffer(util.datagen(bs * nb, 0.3, 0.0, 92), dtype=np.uint8).copy()).cuda()
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for rep in range(3):
+        for src, st, level in ((a, s1, 10), (b, s2, 21), (a, s2, 13), (b, s1, 30)):
+            with torch.cuda.stream(st):
+                outs.append((src, level) + api.compress_blocks_device(src, bs, level))
+    torch.cuda.synchronize()
+    for src, level, dst, sizes, stride in outs:
+        host = src.cpu().numpy()
+        sz = sizes.cpu().numpy()
+        for i in (0, 1, nb // 2, nb - 1):
+            want = util.oracle_compress(host[i * bs:(i + 1) * bs].tobytes(), level)
+            assert dst[i * stride:i * stride + int(sz[i])].cpu().numpy().tobytes() == want, (level, i)
+
+
 def test_roundtrip_with_reference_decoder(L):
     """Full-size property: what the GPU writes decodes with the unmodified reference decoder."""
     ref = util.reference()
