@@ -314,10 +314,19 @@ LZ_DEV void lz_huf_pack_segment(const u8* src, u32 a, u32 b, u8* out, u32 nbytes
         if (first < take) {
             const u32 cnt = take - first < 4u ? take - first : 4u;
             const u32 hi = a + remaining - 1u - first;
-            for (u32 j = 0; j < cnt; j++) {
-                const u32 e = ctab[src[hi - j]];
-                acc |= (u64)(e & 0xFFFu) << len;
-                len += e >> 12;
+            if (cnt == 4u) {                                  // one dword load, four independent table lookups
+                const u32 w4 = lz_ld32(src + hi - 3u);
+                const u32 e0 = ctab[w4 >> 24], e1 = ctab[(w4 >> 16) & 255u], e2 = ctab[(w4 >> 8) & 255u], e3 = ctab[w4 & 255u];
+                acc = (u64)(e0 & 0xFFFu);               len = e0 >> 12;
+                acc |= (u64)(e1 & 0xFFFu) << len;       len += e1 >> 12;
+                acc |= (u64)(e2 & 0xFFFu) << len;       len += e2 >> 12;
+                acc |= (u64)(e3 & 0xFFFu) << len;       len += e3 >> 12;
+            } else {
+                for (u32 j = 0; j < cnt; j++) {
+                    const u32 e = ctab[src[hi - j]];
+                    acc |= (u64)(e & 0xFFFu) << len;
+                    len += e >> 12;
+                }
             }
         }
         const u32 off = lz_wave_scan_excl_add(len);
