@@ -1,4 +1,5 @@
 /* tests/gpu_quick.c — TEST INFRASTRUCTURE: a seconds-long GPU sanity check with a hang watchdog.
+ * usage: gpu_quick [nblocks] [level] [reps] [matchProbaPercent]
  * Runs the product library (liblizard_amd.so, C ABI) on a handful of blocks per level, compares every
  * byte with the oracle (oracle/liblizard_oracle.so) and prints kernel-only throughput of a small
  * batch.  No Python/torch start-up cost: meant to be the FIRST command of every gpurun call so a
@@ -63,7 +64,8 @@ int main(int argc, char** argv)
     g_deadline = 0;
 
     unsigned char* buf = malloc((size_t)nb * bs);
-    for (int b = 0; b < nb; b++) LizardGPU_datagen_host(buf + (size_t)b * bs, bs, 0.5, 0.0, (unsigned)b);
+    double proba = argc > 4 ? atof(argv[4]) / 100.0 : 0.5;   /* datagen match probability in percent (default P50) */
+    for (int b = 0; b < nb; b++) LizardGPU_datagen_host(buf + (size_t)b * bs, bs, proba, 0.0, (unsigned)b);
 
     for (unsigned li = 0; li < sizeof levels / sizeof *levels; li++) {
         int level = levels[li];
