@@ -8,7 +8,7 @@ from test_random_parity import make_case, LEVELS
 from lizard_amd import _lib, api
 L = _lib.lib()
 t0 = time.time(); n = 0; bad = 0
-for seed in range(100, 108):
+for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 100, (int(sys.argv[1]) if len(sys.argv) > 1 else 100) + 8):
     rng = random.Random(seed)
     for trial in range(500):
         data = make_case(rng, 500000)
@@ -27,5 +27,5 @@ for seed in range(100, 108):
             if o != util.oracle_compress(data[i*bs:(i+1)*bs], level):
                 bad += 1; print('BATCH MISMATCH seed', seed, trial, level, bs, i)
     print('seed', seed, 'done', n, 'bad', bad, '%.0fs' % (time.time()-t0), flush=True)
-    if time.time() - t0 > 200: break
+    if time.time() - t0 > (float(sys.argv[2]) if len(sys.argv) > 2 else 200): break
 print('TOTAL', n, 'bad', bad)
