@@ -90,3 +90,55 @@ extern "C" int emul_put_stream_huf(const void* stream, int n, void* out, int* hu
     *huffed = (int)a.huffed;
     return (int)a.result;
 }
+
+
+// Wave-wide helpers of lz_block.h against scalar definitions on one buffer: forward/backward common lengths
+// (lz_count_fwd, lz_count_back, lz_count_both), lz_copy and the scan/reduce primitives.  Returns the number of
+// disagreements (0 = all good).  `pairs` = n triples (P, M, limitOrAnchor) with M < P.
+namespace {
+struct HelperArgs { const u8* buf; u32 n; const u32* trip; u32 ntrip; u8* tmp; u32 bad; };
+void entry_helpers(void* a)
+{
+    HelperArgs* x = (HelperArgs*)a;
+    const u32 lane = lz_lane();
+    u32 bad = 0;
+    for (u32 t = 0; t < x->ntrip; t++) {
+        const u32 P = x->trip[3 * t], M = x->trip[3 * t + 1], lim = x->trip[3 * t + 2];   // M < P <= lim <= n - 16
+        // scalar definitions
+        u32 f = 0; while (P + f < lim && x->buf[P + f] == x->buf[M + f]) f++;
+        const u32 anchor = M > P / 2u ? P / 2u : M / 2u;                                       // some anchor <= P
+        u32 b = 0; while (P - b > anchor && M - b > 0u && x->buf[P - b - 1u] == x->buf[M - b - 1u]) b++;
+        const u32 gf = lz_count_fwd(x->buf, P, M, lim);
+        const u32 gb = lz_count_back(x->buf, P, M, anchor);
+        u32 hf = 0, hb = 0;
+        lz_count_both(x->buf, P, M, lim, anchor, hf, hb);
+        if (gf != f || gb != b || hf != f || hb != b) bad++;
+        // copy of the matched span into tmp and back-check
+        const u32 len = f < 3000u ? f + (t & 7u) : 3000u;
+        lz_copy(x->tmp, x->buf + M, len);
+        lz_wave_sync();
+        u32 diff = 0;
+        for (u32 i = lane; i < len; i += 64u) diff += x->tmp[i] != x->buf[M + i];
+        if (lz_wave_reduce_add(diff)) bad++;
+        lz_wave_sync();
+        // scans: values derived from the data
+        const u32 v = x->buf[(P + lane) % x->n];
+        const u32 ex = lz_wave_scan_excl_add(v);
+        u32 want = 0; for (u32 l = 0; l < lane; l++) want += x->buf[(P + l) % x->n];
+        u32 mx = 0; for (u32 l = 0; l < 64u; l++) { const u32 w = x->buf[(P + l) % x->n]; mx = w > mx ? w : mx; }
+        const u64 wrong = lz_ballot(ex != want);
+        if (wrong || lz_readlane(lz_wave_reduce_max(v), 63u) != mx) bad++;
+    }
+    if (lane == 0) x->bad = bad;
+}
+}  // namespace
+
+extern "C" int emul_check_helpers(const void* buf, int n, const unsigned* triples, int ntriples, unsigned seed)
+{
+    HelperArgs a;
+    a.buf = (const u8*)buf; a.n = (u32)n; a.trip = triples; a.ntrip = (u32)ntriples; a.bad = 0;
+    a.tmp = (u8*)malloc(4096);
+    lzemu::run_wave(entry_helpers, &a, seed);
+    free(a.tmp);
+    return (int)a.bad;
+}

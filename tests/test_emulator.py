@@ -110,3 +110,30 @@ def test_emulated_huffman_stream_vs_oracle():
         assert (out.raw[:r], h.value) == (want, wh), (trial, kind, n)
         huffed += wh
     assert huffed > 10
+
+
+def test_emulated_wave_helpers():
+    """lz_count_fwd / lz_count_back / lz_count_both / lz_copy / scans against scalar definitions on buffers with
+    planted repeats (short, around the 8-, 64- and 512-byte step sizes of the helpers, and long)."""
+    import random
+    import numpy as np
+    emu = util.emulator()
+    rnd = random.Random(5)
+    n = 20000
+    buf = bytearray(util.datagen(n, 0.3, 0.0, 77))
+    triples = []
+    for t in range(160):
+        ln = rnd.choice([0, 1, 7, 8, 9, 63, 64, 65, 100, 511, 512, 513, 520, 1023, 1500, 2600])
+        M = rnd.randrange(70, 6000)
+        P = M + rnd.choice([1, 2, 8, 64, 700]) + rnd.randrange(0, 6000)
+        if P + ln + 40 >= n:
+            continue
+        back = rnd.choice([0, 1, 7, 8, 63, 64, 65, 70])
+        back = min(back, M - 1)
+        buf[P - back:P + ln] = buf[M - back:M + ln]                    # plant the repeat (overlap is fine)
+        lim = rnd.choice([P + ln // 2 + 1, P + ln, P + ln + 30, n - 16])
+        triples += [P, M, min(max(lim, P), n - 16)]
+    arr = (ctypes.c_uint * len(triples))(*triples)
+    emu.emul_check_helpers.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint]
+    for seed in (1, 2, 3):
+        assert emu.emul_check_helpers(bytes(buf), n, arr, len(triples) // 3, seed) == 0
