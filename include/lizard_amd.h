@@ -78,7 +78,8 @@ enum {
     LIZARDGPU_ERR_LEVEL = 2,         /* level not implemented on the GPU path */
     LIZARDGPU_ERR_ARG = 3,           /* bad size / stride / null pointer */
     LIZARDGPU_ERR_HIP = 4,           /* a HIP call failed (see LizardGPU_lastError) */
-    LIZARDGPU_ERR_NOMEM = 5
+    LIZARDGPU_ERR_NOMEM = 5,         /* device or pinned-host allocation failed */
+    LIZARDGPU_ERR_RCCL = 6           /* RCCL could not be loaded or a collective failed */
 };
 
 /* 1 if `compressionLevel` (after the reference's clamp, lib/lizard_compress.c:303-308) runs on the GPU:
@@ -86,12 +87,21 @@ enum {
  * < 16 MiB) and their huff0 twins 30, 31, 34..38, 41, 42 — every row of Lizard_defaultParameters
  * (lib/lizard_common.h:234-284) whose parser is fastSmall, fast, hashChain or priceFast. */
 int LizardGPU_levelSupported(int compressionLevel);
+/* Largest block (bytes) the GPU path takes at this level, 0 if the level has no GPU kernel. */
+size_t LizardGPU_maxBlockSize(int compressionLevel);
 
-/* Select the HIP device used by this process for subsequent calls (default: current device 0).
- * One process per GPU is the intended deployment (torch.distributed / RCCL rank = device). */
-int LizardGPU_setDevice(int device);
+/* Devices.  The library keeps one context per device (arenas, tables, streams, pinned staging), created on first
+ * use and serialised by its own lock; host threads working on different devices run concurrently.
+ * LizardGPU_setDevice selects the device for the CALLING THREAD's later calls and becomes the default of threads
+ * that never selected one (initially device 0); an index outside 0..deviceCount-1 is refused (-LIZARDGPU_ERR_ARG).
+ * Every entry point makes its device current for the duration of the call and restores the caller's.
+ * LizardGPU_shutdown releases every device allocation, stream, pinned buffer and RCCL communicator of the
+ * process (synchronises the devices first); the next call re-creates what it needs. */
+int  LizardGPU_deviceCount(void);
+int  LizardGPU_setDevice(int device);
+void LizardGPU_shutdown(void);
 
-/* Human-readable text of the last HIP failure on the calling thread's context ("" if none). */
+/* Text of the calling thread's last failure ("" after a successful call; thread-local storage). */
 const char* LizardGPU_lastError(void);
 
 /* Compress nBlocks independent blocks that are already RESIDENT IN DEVICE MEMORY.
@@ -112,10 +122,40 @@ int LizardGPU_compressBlocks_device(const void* d_src, size_t nBlocks, size_t bl
                                     void* d_dst, size_t dstStride, uint32_t* d_sizes,
                                     int level, void* stream);
 
-/* Same for HOST-resident buffers: stages src to the device, runs the kernels, copies sizes and payload
- * back (dst slot i at dst + i*dstStride, cSizes[i] bytes valid). Synchronous. */
+/* Same for HOST-resident buffers (dst slot i at dst + i*dstStride, cSizes[i] bytes valid).  Synchronous.
+ * Pipelined in chunks of whole blocks (512 MiB of input, LIZARDGPU_CHUNK_MB overrides): pinned double-buffered
+ * staging, H2D, kernels, device-side compaction of the valid bytes, ONE D2H per chunk — copies of one chunk overlap
+ * the kernels of the next.  A src that is already pinned (hipHostMalloc / hipHostRegister) is read by DMA directly.
+ * _host_packed writes the compressed blocks back to back instead: block i at dst + offsets[i], cSizes[i] bytes,
+ * offsets[nBlocks] = total (offsets / cSizes may be NULL); -LIZARDGPU_ERR_ARG if dstCapacity is too small. */
 int LizardGPU_compressBlocks_host(const void* src, size_t nBlocks, size_t blockSize, size_t lastBlockSize,
                                   void* dst, size_t dstStride, uint32_t* cSizes, int level);
+int LizardGPU_compressBlocks_host_packed(const void* src, size_t nBlocks, size_t blockSize, size_t lastBlockSize,
+                                         void* dst, size_t dstCapacity, uint64_t* offsets, uint32_t* cSizes, int level);
+
+/* ---- several GPUs ----
+ * Blocks are independent: rank r of R owns the contiguous range LizardGPU_shardRange gives it, no halo; the one
+ * exchange is the RCCL all-gather of the per-block compressed sizes (uint32 per block, over xGMI inside a node),
+ * followed by an exclusive prefix sum = byte offset of every block in the concatenated output.
+ *
+ * One process driving nDevices GPUs: device devices[r] (r if devices == NULL) holds its blocks back to back at d_src[r]
+ * and gets its slots at d_dst[r]; on return (synchronous) every device's d_allSizes[r][0..nBlocks) holds ALL sizes
+ * and d_offsets[r][0..nBlocks] the offsets (last entry = total).  The ragged last block belongs to the last rank.
+ *
+ * One process per GPU (torchrun): rank 0 calls LizardGPU_commUniqueId (128 bytes), the launcher's transport carries
+ * them to the other ranks, every rank calls LizardGPU_commInitRank once, then LizardGPU_gatherSizes_device after each
+ * batch: d_localSizes = this rank's shard (may already sit at d_allSizes + first), enqueued on `stream`.
+ * LizardGPU_offsetsFromSizes is the host form of the prefix sum (offsets[nBlocks] = total). */
+void LizardGPU_shardRange(size_t nBlocks, int rank, int nRanks, size_t* first, size_t* count);
+void LizardGPU_offsetsFromSizes(const uint32_t* sizes, size_t nBlocks, uint64_t* offsets);
+int  LizardGPU_compressBlocks_sharded(int nDevices, const int* devices, const void* const* d_src, size_t nBlocks,
+                                      size_t blockSize, size_t lastBlockSize, void* const* d_dst, size_t dstStride,
+                                      uint32_t* const* d_allSizes, uint64_t* const* d_offsets, int level);
+int  LizardGPU_commUniqueId(void* id128);
+int  LizardGPU_commInitRank(const void* id128, int nRanks, int rank);
+int  LizardGPU_gatherSizes_device(const uint32_t* d_localSizes, size_t nBlocks, uint32_t* d_allSizes,
+                                  uint64_t* d_offsets, void* stream);
+int  LizardGPU_commDestroy(void);
 
 /* Synthetic input, the reference's benchmark generator (programs/datagen.c:153 RDG_genBuffer).
  * Host: fills buffer[0..size) exactly like RDG_genBuffer(buffer, size, matchProba, litProba, seed).
@@ -125,60 +165,80 @@ void LizardGPU_datagen_host(void* buffer, size_t size, double matchProba, double
 int  LizardGPU_datagen_device(void* d_dst, size_t nBlocks, size_t blockSize, double matchProba, double litProba,
                               unsigned seed0, void* stream);
 
-/* Kernel-only duration of the most recent LizardGPU_compressBlocks_* call measured with HIP events on
- * the launch stream, in milliseconds (blocks until that launch finished). < 0 if unavailable. */
+/* Kernel-only duration of the most recent LizardGPU_compressBlocks_* call on the selected device, measured with HIP
+ * events on the launch stream, in milliseconds (blocks until that launch finished; host-buffer calls: the sum over
+ * their chunks). < 0 if unavailable. */
 float LizardGPU_lastKernelMs(void);
 
 /* Number of resident waves (= blocks compressed concurrently) the launcher uses on this device. */
 int LizardGPU_residentWaves(void);
 
 /* =====================================================================================================
- * Part 3 — one-shot frame production on the batched GPU path.
+ * Part 3 — frame production on the batched GPU path.
  *
- * LizardGPU_compressFrame() writes byte for byte what the reference's LizardF_compressFrame()
- * (lib/lizard_frame.h:134, lib/lizard_frame.c:260-316) writes for the same preferences in
- * independent-block mode (reference built with -DLIZARD_RESET_MEM, the zero-state oracle): frame header,
- * LE32-sized block records (bit 31 = stored raw), end mark, XXH32 content checksum.  Every block of the
- * frame goes through the batched kernels instead of one Lizard_compress_extState call per block.
- * The reference keeps frame compression and decompression in ONE object (lizard_frame.c), so these
- * symbols are prefixed LizardGPU_ and coexist with a linked reference LizardF_* (INTEGRATION.md §3).
+ * A twin of the reference's frame COMPRESSOR: LizardGPU_compressBegin / _compressUpdate / _flush / _compressEnd
+ * follow lib/lizard_frame.c:362-424, :501-599, :610-637, :651-677 call for call, and LizardGPU_compressFrame is built
+ * on them like LizardF_compressFrame (lizard_frame.c:260-316).  They write byte for byte what the reference writes for
+ * the same preferences and the same sequence of calls in independent-block mode (reference built with
+ * -DLIZARD_RESET_MEM, the zero-state oracle): frame header, LE32-sized block records (bit 31 = stored raw), end
+ * mark, XXH32 content checksum.  Every run of blocks an Update call covers is ONE batch through the block kernels,
+ * and the block records are assembled on the device (prefix sum of sizes + compaction), so only the frame body
+ * crosses PCIe, once.  The content checksum runs on a host thread beside the GPU work.
+ * The reference keeps frame compression and decompression in ONE object (lizard_frame.c), so these symbols are
+ * prefixed LizardGPU_ and coexist with a linked reference LizardF_* (INTEGRATION.md §2).
  *
- * LizardGPU_framePrefs_t is layout-identical to LizardF_preferences_t (lib/lizard_frame.h:111-125): a
- * caller holding the reference type passes (const LizardGPU_framePrefs_t*)&prefs.
- * Return value: bytes written, or an error code that LizardGPU_frameIsError() recognises; codes are the
+ * LizardGPU_framePrefs_t is layout-identical to LizardF_preferences_t (lib/lizard_frame.h:111-125): a caller
+ * holding the reference type passes (const LizardGPU_framePrefs_t*)&prefs.
+ * Size_t results: bytes written, or an error code that LizardGPU_frameIsError() recognises; codes are the
  * reference's (size_t)-LizardF_ERROR_* values (lib/lizard_frame_static.h:57-67).  Refused, never emulated:
- * linked-block frames larger than one block (blockMode_invalid) and levels without a GPU kernel
- * (compressionLevel_invalid).
+ * linked-block frames larger than one block (blockMode_invalid), levels without a GPU kernel
+ * (compressionLevel_invalid), block sizes above LizardGPU_maxBlockSize(level) (maxBlockSize_invalid: 4 MiB at levels
+ * 11/31/13-17/34-38, 16 MiB excluded at 21/22/41/42) and skippable frames (frameType_unknown).
  * ===================================================================================================== */
 typedef struct {
     unsigned           blockSizeID;          /* LizardF_blockSizeID_t: 0 = default (128 KiB), 1..7 = 128K,256K,1M,4M,16M,64M,256M */
     unsigned           blockMode;            /* LizardF_blockMode_t: 0 = linked, 1 = independent */
     unsigned           contentChecksumFlag;  /* 0 / 1 */
     unsigned           frameType;            /* 0 = frame */
-    unsigned long long contentSize;          /* != 0: the header carries srcSize */
+    unsigned long long contentSize;          /* != 0: the header carries the content size */
     unsigned           reserved[2];
 } LizardGPU_frameInfo_t;                     /* == LizardF_frameInfo_t */
 
 typedef struct {
     LizardGPU_frameInfo_t frameInfo;
     int      compressionLevel;               /* clamped like Lizard_createStream (lib/lizard_compress.c:303-308) */
-    unsigned autoFlush;                      /* ignored: one-shot frames always flush (lizard_frame.c:283) */
+    unsigned autoFlush;                      /* 1 = every Update call ends on a block boundary (no buffering) */
     unsigned reserved[4];
 } LizardGPU_framePrefs_t;                    /* == LizardF_preferences_t */
 
 enum {                                       /* LizardF_errorCodes, lib/lizard_frame_static.h:57-67 */
     LIZARDGPU_FRAME_ERR_GENERIC = 1, LIZARDGPU_FRAME_ERR_maxBlockSize_invalid = 2, LIZARDGPU_FRAME_ERR_blockMode_invalid = 3,
     LIZARDGPU_FRAME_ERR_compressionLevel_invalid = 5, LIZARDGPU_FRAME_ERR_allocation_failed = 9,
-    LIZARDGPU_FRAME_ERR_dstMaxSize_tooSmall = 11, LIZARDGPU_FRAME_ERR_maxCode = 19
+    LIZARDGPU_FRAME_ERR_dstMaxSize_tooSmall = 11, LIZARDGPU_FRAME_ERR_frameType_unknown = 13,
+    LIZARDGPU_FRAME_ERR_frameSize_wrong = 14, LIZARDGPU_FRAME_ERR_maxCode = 19
 };
 
+/* replaces LizardF_isError, lib/lizard_frame.h:59 / lizard_frame.c:179 */
+unsigned LizardGPU_frameIsError(size_t code);
 /* replaces LizardF_compressFrameBound, lib/lizard_frame.h:122 / lizard_frame.c:229 (same value) */
 size_t LizardGPU_compressFrameBound(size_t srcSize, const LizardGPU_framePrefs_t* preferencesPtr);
 /* replaces LizardF_compressFrame, lib/lizard_frame.h:134 / lizard_frame.c:260 (host buffers, synchronous) */
 size_t LizardGPU_compressFrame(void* dstBuffer, size_t dstMaxSize, const void* srcBuffer, size_t srcSize,
                                const LizardGPU_framePrefs_t* preferencesPtr);
-/* replaces LizardF_isError, lib/lizard_frame.h:59 / lizard_frame.c:179 */
-unsigned LizardGPU_frameIsError(size_t code);
+
+/* Streaming form.  LizardGPU_cctx_t replaces LizardF_compressionContext_t (lib/lizard_frame.h:145); the functions
+ * replace LizardF_createCompressionContext / _freeCompressionContext (:157-158, int result: 0 or -LIZARDGPU_FRAME_ERR_*),
+ * LizardF_compressBegin (:169), LizardF_compressBound (:178), LizardF_compressUpdate (:190), LizardF_flush (:202) and
+ * LizardF_compressEnd (:213).  The reference's LizardF_compressOptions_t only carries stableSrc, which matters to
+ * linked blocks alone, so the argument is dropped. */
+typedef struct LizardGPU_cctx_s LizardGPU_cctx_t;
+int    LizardGPU_createCompressionContext(LizardGPU_cctx_t** cctxPtr);
+int    LizardGPU_freeCompressionContext(LizardGPU_cctx_t* cctx);
+size_t LizardGPU_compressBegin(LizardGPU_cctx_t* cctx, void* dstBuffer, size_t dstMaxSize, const LizardGPU_framePrefs_t* preferencesPtr);
+size_t LizardGPU_compressBound(size_t srcSize, const LizardGPU_framePrefs_t* preferencesPtr);
+size_t LizardGPU_compressUpdate(LizardGPU_cctx_t* cctx, void* dstBuffer, size_t dstMaxSize, const void* srcBuffer, size_t srcSize);
+size_t LizardGPU_flush(LizardGPU_cctx_t* cctx, void* dstBuffer, size_t dstMaxSize);
+size_t LizardGPU_compressEnd(LizardGPU_cctx_t* cctx, void* dstBuffer, size_t dstMaxSize);
 
 #ifdef __cplusplus
 }

@@ -58,12 +58,28 @@ def lib():
     L.LizardGPU_datagen_host.restype = None
     L.LizardGPU_datagen_device.argtypes = [c.c_void_p, c.c_size_t, c.c_size_t, c.c_double, c.c_double, c.c_uint, c.c_void_p]
     L.LizardGPU_datagen_device.restype = c.c_int
+    L.LizardGPU_compressBlocks_host_packed.argtypes = [c.c_void_p, c.c_size_t, c.c_size_t, c.c_size_t, c.c_void_p,
+                                                       c.c_size_t, c.c_void_p, c.c_void_p, c.c_int]
+    L.LizardGPU_compressBlocks_host_packed.restype = c.c_int
+    L.LizardGPU_maxBlockSize.argtypes = [c.c_int]; L.LizardGPU_maxBlockSize.restype = c.c_size_t
+    L.LizardGPU_deviceCount.restype = c.c_int
+    L.LizardGPU_shutdown.restype = None
+    L.LizardGPU_shardRange.argtypes = [c.c_size_t, c.c_int, c.c_int, c.c_void_p, c.c_void_p]; L.LizardGPU_shardRange.restype = None
+    L.LizardGPU_offsetsFromSizes.argtypes = [c.c_void_p, c.c_size_t, c.c_void_p]; L.LizardGPU_offsetsFromSizes.restype = None
+    L.LizardGPU_compressBlocks_sharded.argtypes = [c.c_int, c.c_void_p, c.c_void_p, c.c_size_t, c.c_size_t, c.c_size_t,
+                                                   c.c_void_p, c.c_size_t, c.c_void_p, c.c_void_p, c.c_int]
+    L.LizardGPU_compressBlocks_sharded.restype = c.c_int
+    L.LizardGPU_commUniqueId.argtypes = [c.c_void_p]; L.LizardGPU_commUniqueId.restype = c.c_int
+    L.LizardGPU_commInitRank.argtypes = [c.c_void_p, c.c_int, c.c_int]; L.LizardGPU_commInitRank.restype = c.c_int
+    L.LizardGPU_gatherSizes_device.argtypes = [c.c_void_p, c.c_size_t, c.c_void_p, c.c_void_p, c.c_void_p]
+    L.LizardGPU_gatherSizes_device.restype = c.c_int
+    L.LizardGPU_commDestroy.restype = c.c_int
     _lib = L
     return L
 
 
 _ERR = {1: "no HIP device", 2: "level not implemented on the GPU path", 3: "bad argument", 4: "HIP call failed",
-        5: "out of memory"}
+        5: "out of memory", 6: "RCCL failure"}
 
 
 def check(rc, what):

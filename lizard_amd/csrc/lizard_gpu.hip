@@ -3,16 +3,24 @@
 // Launch geometry: ONE wavefront per Lizard API block.  The grid is persistent — one workgroup of up to
 // 16 independent waves per CU (they never synchronise with each other) — and every wave pulls block indices
 // from a device counter, so tail blocks do not strand CUs.  Each wave owns a hash table (LDS slice or
-// global-memory slot, see lz_wave_main) and a scratch slot in a global arena (sequence list / stream staging,
+// global-memory slot, see lz_wave_main) and a scratch slot in a global arena (sequence list / Huffman staging,
 // written and re-read once per sub-block).  Blocks never communicate: no inter-workgroup synchronisation.
+//
+// Host side of this file: one context PER DEVICE (arenas, tables, streams, pinned staging), a per-thread device
+// selection and error text, the pipelined host-buffer path (pinned double-buffered staging, device-side
+// compaction of the compressed blocks, one D2H per chunk) and the single-process multi-device entry with an
+// RCCL all-gather of the per-block sizes (lizard_shard.h).
 #include <hip/hip_runtime.h>
 #include <pthread.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/lizard_amd.h"
+#include "lizard_gpu_shim.h"
 #include "lz_block.h"
 #include "lz_datagen.h"
+#include "lz_pack.h"
 
 namespace {
 
@@ -20,8 +28,8 @@ struct LzBatch {
     const u8* src;  u64 blockSize;  u32 nBlocks;  u32 lastBlockSize;
     u8* dst;        u64 dstStride;  u32* sizes;   u32 level;
     u8* scratch;    u32* counter;
-    u8* tables;     // levels 11/31: one LZ_TABWIDE_BYTES(18) hash table per resident wave (global memory);
-                    // hashChain levels: one LZ_HC_SLOT_BYTES(maxBlock) slot per resident wave
+    u8* tables;     // per resident wave, for the waves whose hash table is not in LDS: levels 10/30/21/41 a 64 KiB slot,
+                    // levels 11/31/22/42 LZ_TABWIDE_BYTES(18), hashChain levels LZ_HC_SLOT_BYTES(maxBlock)
     u64 tableStride;
 };
 
@@ -30,19 +38,30 @@ struct LzBatch {
 // apiece, so only twelve fit in a CU's 160 KiB (the occupancy API, which divides raw sizes, says thirteen).
 // Instead ONE workgroup per CU carries W waves and private slices of one allocation; NLDS of them keep their
 // hash table in LDS, the others in a global-memory slot (DESIGN.md section 4 lists the split per level).
+// The splits are compile-time knobs so that tuning variants can be built side by side (lizard_amd/variants).
+#ifndef LZ_WAVES_FAST
 #define LZ_WAVES_FAST      16
+#endif
+#ifndef LZ_NLDS_FAST
 #define LZ_NLDS_FAST       12
+#endif
+#ifndef LZ_WAVES_FAST_HUF
 #define LZ_WAVES_FAST_HUF  16
+#endif
+#ifndef LZ_NLDS_FAST_HUF
 #define LZ_NLDS_FAST_HUF   5
+#endif
 #define LZ_WAVES_FASTLDS      13             // all tables in LDS (blocks above 4 MiB)
 #define LZ_WAVES_FASTLDS_HUF  9
+#define LZ_MAX_WAVES          16             // scratch / table slots per CU
 
-// NLDS of the W waves keep their hash table in LDS, the others in the wave's global-memory slot (a.tables).
-template <int PARSER, int HASHLOG, int AUX, bool HUF, int W, int WSWORDS, int NLDS = (HASHLOG > 14 ? 0 : W)>
+// NLDS of the W waves keep their hash table in LDS (form LDSKIND), the others in the wave's global-memory slot.
+template <int PARSER, int HASHLOG, int AUX, bool HUF, int W, int WSWORDS, int NLDS = (HASHLOG > 14 ? 0 : W), u32 LDSKIND = LZ_TABKIND_LDS>
 __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
 {
-    struct Slice { u64 ring[PARSER != LZ_PARSER_PRICEFAST ? LZ_SEQ_RING : 1]; u32 ws[WSWORDS]; };
-    __shared__ u32 ldsTables[NLDS ? NLDS : 1][NLDS ? LZ_TAB_BYTES(HASHLOG) / 4u : 1];
+    struct Slice { u64 ring[LZ_SEQ_RING]; u32 ws[WSWORDS]; };
+    constexpr u32 kTabWords = (LDSKIND == LZ_TABKIND_LDS18 ? LZ_TAB18_BYTES(HASHLOG) : LZ_TAB_BYTES(HASHLOG)) / 4u + 1u;
+    __shared__ u32 ldsTables[NLDS ? NLDS : 1][NLDS ? kTabWords : 1];
     __shared__ Slice lds[W];
     // fast parser, mixed residency: the global-table waves need the round tag array of LzTabWide; with the Huffman
     // stage it aliases their workspace, without it they get their own 2 KiB here
@@ -51,21 +70,21 @@ __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
     __shared__ u32 wideTags[kOwnTags ? W - NLDS : 1][kOwnTags ? (1u << LZ_WIDE_TAGLOG) / 4u : 1];
     const u32 wave = lz_uniform(threadIdx.x >> 6);               // readfirstlane: the wave index (and everything derived from it) lives in SGPRs
     Slice& my = lds[wave];
-    const u64 slot = (u64)blockIdx.x * W + wave;
+    const u64 slot = (u64)blockIdx.x * LZ_MAX_WAVES + wave;
     u8* scratch = a.scratch + slot * LZ_SCRATCH_BYTES;
     void* tableMem;
     if constexpr (NLDS == W)      tableMem = (void*)ldsTables[wave];
     else if constexpr (NLDS == 0) tableMem = (void*)(a.tables + slot * a.tableStride);
-    else tableMem = wave < (u32)NLDS ? (void*)ldsTables[wave] : (void*)(a.tables + slot * a.tableStride);   // (priceFast: u32 slots there)
-    const bool tab32 = NLDS != W && wave >= (u32)NLDS;               // my table is in global memory, u32 slots
-    u8* const ws = (kOwnTags && tab32) ? (u8*)wideTags[kOwnTags ? wave - NLDS : 0] : (u8*)my.ws;
+    else tableMem = wave < (u32)NLDS ? (void*)ldsTables[wave] : (void*)(a.tables + slot * a.tableStride);
+    const u32 tabKind = (NLDS != W && wave >= (u32)NLDS) ? LZ_TABKIND_GLOBAL : LDSKIND;
+    u8* const ws = (kOwnTags && tabKind == LZ_TABKIND_GLOBAL) ? (u8*)wideTags[kOwnTags ? wave - NLDS : 0] : (u8*)my.ws;
     for (;;) {
         lz_converge();
         const u32 b = lz_claim_index(a.counter);
         if (b >= a.nBlocks) break;
         const u32 n = (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
         const u32 c = lz_compress_block<PARSER, HASHLOG, AUX, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
-                                                                  a.level, tableMem, ws, scratch, my.ring, tab32);
+                                                                  a.level, tableMem, ws, scratch, my.ring, tabKind);
         if (lz_lane() == 0) a.sizes[b] = c;
         lz_converge();
     }
@@ -104,25 +123,57 @@ __global__ __launch_bounds__(64 * LZ_WAVES_HC) void lz_hashchain_kernel(LzBatch 
     lz_wave_main<LZ_PARSER_HASHCHAIN, 18, SEARCHLEN, HUF, LZ_WAVES_HC, (HUF ? LZ_HUF_WS_WORDS : (1u << LZ_HC_TAGLOG) / 4u)>(a);
 }
 
-// levels 21 / 41: priceFast + LIZv1, 2^14-slot table of 24-bit positions (48 KiB).  Only three such tables fit a
-// CU's LDS, and the parse is a latency chain, so the workgroup carries 16 waves anyway: NLDS of them keep the
-// table in LDS, the others in their global-memory slot (L2 / Infinity Cache; ~5x slower per wave, but there are
-// many more of them).  LDS: 2 x 48 KiB + 16 x 2 KiB tag arrays (level 21), 1 x 48 KiB + 16 x 5.3 KiB Huffman
-// workspaces (level 41).
-#define LZ_WAVES_PF 16
+// levels 21 / 41: priceFast + LIZv1, 2^14-slot table.  The parse is a latency chain, so throughput follows the
+// number of resident waves, and a wave whose table is in LDS is several times faster than one that keeps it in a
+// global-memory slot (there every probe is a memory-side sector).  Two forms, chosen by block size:
+//   SMALL (blocks <= 256 KiB, the benchmark configuration): 18-bit positions packed into 36 KiB (LzTab18) — four
+//         tables per CU (two beside the sixteen 5.3 KiB Huffman workspaces of level 41);
+//   general (blocks < 16 MiB): 24-bit positions, 48 KiB (LzTabPf24) — two tables per CU (one at level 41).
+// The remaining waves of the workgroup keep u32 slots in their 64 KiB global-memory slot (LzTab32).
+#ifndef LZ_PF_W
+#define LZ_PF_W 16
+#endif
+#ifndef LZ_PF_NLDS
+#define LZ_PF_NLDS 2
+#endif
+#ifndef LZ_PF_NLDS_HUF
+#define LZ_PF_NLDS_HUF 1
+#endif
+#ifndef LZ_PF_TAGLOG
 #define LZ_PF_TAGLOG 11
+#endif
+#ifndef LZ_PF18_W
+#define LZ_PF18_W 16
+#endif
+#ifndef LZ_PF18_NLDS
+#define LZ_PF18_NLDS 4
+#endif
+#ifndef LZ_PF18_TAGLOG
+#define LZ_PF18_TAGLOG 9
+#endif
+#ifndef LZ_PF18_W_HUF
+#define LZ_PF18_W_HUF 15
+#endif
+#ifndef LZ_PF18_NLDS_HUF
+#define LZ_PF18_NLDS_HUF 2
+#endif
 #define LZ_PF_SLOT_BYTES 65536u
-template <bool HUF>
-__global__ __launch_bounds__(64 * LZ_WAVES_PF) void lz_pricefast14_kernel(LzBatch a)
+template <bool HUF, bool SMALL>
+__global__ __launch_bounds__(64 * (SMALL ? (HUF ? LZ_PF18_W_HUF : LZ_PF18_W) : LZ_PF_W)) void lz_pricefast14_kernel(LzBatch a)
 {
-    lz_wave_main<LZ_PARSER_PRICEFAST, 14, LZ_PF_TAGLOG, HUF, LZ_WAVES_PF, (HUF ? LZ_HUF_WS_WORDS : (1u << LZ_PF_TAGLOG) / 4u), (HUF ? 1 : 2)>(a);
+    if constexpr (SMALL)
+        lz_wave_main<LZ_PARSER_PRICEFAST, 14, (HUF ? 11 : LZ_PF18_TAGLOG), HUF, (HUF ? LZ_PF18_W_HUF : LZ_PF18_W),
+                     (HUF ? LZ_HUF_WS_WORDS : (1u << LZ_PF18_TAGLOG) / 4u), (HUF ? LZ_PF18_NLDS_HUF : LZ_PF18_NLDS), LZ_TABKIND_LDS18>(a);
+    else
+        lz_wave_main<LZ_PARSER_PRICEFAST, 14, LZ_PF_TAGLOG, HUF, LZ_PF_W, (HUF ? LZ_HUF_WS_WORDS : (1u << LZ_PF_TAGLOG) / 4u),
+                     (HUF ? LZ_PF_NLDS_HUF : LZ_PF_NLDS)>(a);
 }
 
 // levels 22 / 42: priceFast + LIZv1 with a 2^18-slot table: 1 MiB of u32 slots per wave, all in global memory
 template <bool HUF>
-__global__ __launch_bounds__(64 * LZ_WAVES_PF) void lz_pricefast18_kernel(LzBatch a)
+__global__ __launch_bounds__(64 * LZ_PF_W) void lz_pricefast18_kernel(LzBatch a)
 {
-    lz_wave_main<LZ_PARSER_PRICEFAST, 18, LZ_PF_TAGLOG, HUF, LZ_WAVES_PF, (HUF ? LZ_HUF_WS_WORDS : (1u << LZ_PF_TAGLOG) / 4u), 0>(a);
+    lz_wave_main<LZ_PARSER_PRICEFAST, 18, LZ_PF_TAGLOG, HUF, LZ_PF_W, (HUF ? LZ_HUF_WS_WORDS : (1u << LZ_PF_TAGLOG) / 4u), 0>(a);
 }
 
 // synthetic input: one thread per block, block b = RDG_genBuffer(blockSize, P, seed0 + b)
@@ -134,159 +185,126 @@ __global__ __launch_bounds__(64) void lz_datagen_kernel(u8* dst, u64 nBlocks, u6
 }
 
 // ------------------------------------------------------------------------------------------------
+// One stage of the host-buffer pipeline: pinned staging on the host side, input / slot / packed buffers on the
+// device side, its own stream.  Two stages alternate so that the copies of one chunk overlap the kernels of the other.
+struct Stage {
+    hipStream_t stream = nullptr;
+    hipEvent_t  k0 = nullptr, k1 = nullptr, meta = nullptr, done = nullptr;
+    u8*  h_in = nullptr;     size_t h_in_cap = 0;        // pinned
+    u8*  h_out = nullptr;    size_t h_out_cap = 0;       // pinned
+    u32* h_sizes = nullptr;  u64* h_offsets = nullptr;   size_t h_meta_cap = 0;   // pinned, nBlocks (+1)
+    u8*  d_in = nullptr;     size_t d_in_cap = 0;
+    u8*  d_slots = nullptr;  size_t d_slots_cap = 0;
+    u8*  d_packed = nullptr; size_t d_packed_cap = 0;
+    u32* d_sizes = nullptr;  u64* d_offsets = nullptr;   size_t d_meta_cap = 0;
+};
+
 struct Ctx {
+    bool  ready = false;
     int   device = -1;
     int   cus = 0;
-    int   waves = 0;            // persistent grid size (level 10)
-    int   wavesHuf = 0;         // persistent grid size (level 30: larger LDS workspace)
-    int   wavesPf = 0, wavesPfHuf = 0;   // levels 21 / 41
-    u8*   tables = nullptr;     // levels 11 / 31, allocated on first use
-    u8*   pfTables = nullptr;   // levels 21 / 41: 64 KiB per resident wave for the waves whose table is not in LDS
+    u8*   tables = nullptr;     // levels 11/31/22/42, allocated on first use
+    u8*   pfTables = nullptr;   // levels 10/30/21/41: 64 KiB per resident wave for the waves whose table is not in LDS
     u8*   hcSlots = nullptr;    // hashChain levels, allocated (and zeroed) on first use / when a larger block size arrives
     size_t hcMaxBlock = 0;
     u8*   scratch = nullptr;
     u32*  counter = nullptr;
+    u8*   d_lt = nullptr;       // datagen literal table
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool  timed = false;
-    // host-path staging
-    u8*   d_src = nullptr;  size_t d_src_cap = 0;
-    u8*   d_dst = nullptr;  size_t d_dst_cap = 0;
-    u32*  d_sizes = nullptr; size_t d_sizes_cap = 0;
-    hipStream_t stream = nullptr;
-    char  err[256] = {0};
+    float hostKernelMs = -1.0f; // sum over the chunks of the last host-buffer call (< 0: last call was a device call)
+    Stage stage[2];
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
 };
 
-Ctx g_ctx;
-int g_want_device = 0;
-pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
+#define LZ_MAX_DEVICES 16
+Ctx g_ctx[LZ_MAX_DEVICES];
+int g_default_device = 0;                              // process default (the last LizardGPU_setDevice of any thread)
+pthread_mutex_t g_sel_mu = PTHREAD_MUTEX_INITIALIZER;
+thread_local int  t_device = -1;                       // calling thread's selection, -1 = process default
+thread_local char t_err[256] = {0};
+size_t g_chunk_bytes = 0;                              // host pipeline chunk (input bytes), 0 = not read yet
+
+void set_err(const char* fmt, const char* a, const char* b)
+{
+    snprintf(t_err, sizeof t_err, fmt, a, b);
+}
 
 #define LZ_HIP(call)                                                                                   \
     do {                                                                                               \
         hipError_t e_ = (call);                                                                        \
         if (e_ != hipSuccess) {                                                                        \
-            snprintf(g_ctx.err, sizeof g_ctx.err, "%s failed: %s", #call, hipGetErrorString(e_));      \
-            return -LIZARDGPU_ERR_HIP;                                                                 \
+            set_err("%s failed: %s", #call, hipGetErrorString(e_));                                    \
+            return e_ == hipErrorOutOfMemory ? -LIZARDGPU_ERR_NOMEM : -LIZARDGPU_ERR_HIP;              \
         }                                                                                              \
     } while (0)
 
-int ctx_init_locked()
+int selected_device()
 {
-    if (g_ctx.device == g_want_device && g_ctx.scratch) return 0;
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
-        snprintf(g_ctx.err, sizeof g_ctx.err, "no HIP device visible");
-        return -LIZARDGPU_ERR_NO_DEVICE;
-    }
-    LZ_HIP(hipSetDevice(g_want_device));
-    hipDeviceProp_t prop;
-    LZ_HIP(hipGetDeviceProperties(&prop, g_want_device));
-    g_ctx.cus = prop.multiProcessorCount;
-    g_ctx.waves = g_ctx.cus * LZ_WAVES_FAST18;            // scratch slots for the largest W (one workgroup per CU, see lz_wave_main)
-    g_ctx.wavesHuf = g_ctx.cus * LZ_WAVES_FAST_HUF;
-    g_ctx.wavesPf = g_ctx.wavesPfHuf = g_ctx.cus * LZ_WAVES_PF;
-    LZ_HIP(hipMalloc((void**)&g_ctx.scratch, (size_t)g_ctx.waves * LZ_SCRATCH_BYTES));
-#ifdef LZ_PROFILE
-    LZ_HIP(hipMemset(g_ctx.scratch, 0, (size_t)g_ctx.waves * LZ_SCRATCH_BYTES));
-#endif
-    LZ_HIP(hipMalloc((void**)&g_ctx.counter, 64));
-    LZ_HIP(hipEventCreate(&g_ctx.ev0));
-    LZ_HIP(hipEventCreate(&g_ctx.ev1));
-    LZ_HIP(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
-    g_ctx.device = g_want_device;
-    return 0;
+    if (t_device >= 0) return t_device;
+    pthread_mutex_lock(&g_sel_mu);
+    const int d = g_default_device;
+    pthread_mutex_unlock(&g_sel_mu);
+    return d;
 }
 
-int launch_locked(const void* d_src, size_t nBlocks, size_t blockSize, size_t lastBlockSize, void* d_dst,
-                  size_t dstStride, u32* d_sizes, int level, hipStream_t stream)
+// Locks the selected device's context and makes that device current for the calling thread (HIP's current device
+// is per thread); restores the caller's device on exit.
+struct Guard {
+    Ctx* c = nullptr;
+    int  saved = -1, rc = 0;
+    Guard()
+    {
+        t_err[0] = 0;
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+            (void)hipGetLastError();
+            snprintf(t_err, sizeof t_err, "no HIP device visible");
+            rc = -LIZARDGPU_ERR_NO_DEVICE; return;
+        }
+        const int dev = selected_device();
+        if (dev < 0 || dev >= count || dev >= LZ_MAX_DEVICES) {
+            snprintf(t_err, sizeof t_err, "device %d out of range (%d visible)", dev, count);
+            rc = -LIZARDGPU_ERR_ARG; return;
+        }
+        if (hipGetDevice(&saved) != hipSuccess) saved = -1;
+        c = &g_ctx[dev];
+        pthread_mutex_lock(&c->mu);
+        if (hipSetDevice(dev) != hipSuccess) { snprintf(t_err, sizeof t_err, "hipSetDevice(%d) failed", dev); rc = -LIZARDGPU_ERR_HIP; return; }
+        c->device = dev;
+    }
+    ~Guard()
+    {
+        if (c) pthread_mutex_unlock(&c->mu);
+        if (saved >= 0) (void)hipSetDevice(saved);
+    }
+};
+
+int ctx_init(Ctx& c)
 {
-    if (!LizardGPU_levelSupported(level)) return -LIZARDGPU_ERR_LEVEL;
-    if (!d_src || !d_dst || !d_sizes || nBlocks == 0 || nBlocks > 0xFFFFFFFFu) return -LIZARDGPU_ERR_ARG;
-    if (blockSize == 0 || blockSize > LIZARD_MAX_INPUT_SIZE || lastBlockSize == 0 || lastBlockSize > blockSize) return -LIZARDGPU_ERR_ARG;
-    if (dstStride < (size_t)LIZARD_COMPRESSBOUND((int)blockSize)) return -LIZARDGPU_ERR_ARG;
-    if ((level == 21 || level == 41 || level == 22 || level == 42) && blockSize >= (1u << 24) - 1u) {      // 24-bit table positions (lz_pricefast.h)
-        snprintf(g_ctx.err, sizeof g_ctx.err, "levels 21/22/41/42: blocks of 16 MiB or more are not supported on the GPU path");
-        return -LIZARDGPU_ERR_ARG;
+    if (c.ready) return 0;
+    hipDeviceProp_t prop;
+    LZ_HIP(hipGetDeviceProperties(&prop, c.device));
+    c.cus = prop.multiProcessorCount;
+    LZ_HIP(hipMalloc((void**)&c.scratch, (size_t)c.cus * LZ_MAX_WAVES * LZ_SCRATCH_BYTES));   // one slot per resident wave (one workgroup per CU)
+#ifdef LZ_PROFILE
+    LZ_HIP(hipMemset(c.scratch, 0, (size_t)c.cus * LZ_MAX_WAVES * LZ_SCRATCH_BYTES));
+#endif
+    LZ_HIP(hipMalloc((void**)&c.counter, 64));
+    LZ_HIP(hipEventCreate(&c.ev0));
+    LZ_HIP(hipEventCreate(&c.ev1));
+    for (Stage& s : c.stage) {
+        LZ_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        LZ_HIP(hipEventCreate(&s.k0)); LZ_HIP(hipEventCreate(&s.k1));
+        LZ_HIP(hipEventCreateWithFlags(&s.meta, hipEventDisableTiming));
+        LZ_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     }
-    int rc = ctx_init_locked();
-    if (rc) return rc;
-    LzBatch a;
-    a.src = (const u8*)d_src; a.blockSize = blockSize; a.nBlocks = (u32)nBlocks; a.lastBlockSize = (u32)lastBlockSize;
-    a.dst = (u8*)d_dst; a.dstStride = dstStride; a.sizes = d_sizes; a.level = (u32)level;
-    a.scratch = g_ctx.scratch; a.counter = g_ctx.counter; a.tables = g_ctx.tables;
-    int lv = level > LIZARD_MAX_CLEVEL ? LIZARD_MAX_CLEVEL : level;
-    if (lv < LIZARD_MIN_CLEVEL) lv = LIZARD_DEFAULT_CLEVEL;
-    a.level = (u32)lv;
-    // one workgroup of W waves per CU; small batches launch only as many workgroups as they have blocks for
-    const bool hcLevel = (lv >= 13 && lv <= 17) || (lv >= 34 && lv <= 38);
-    const bool fastMixed = blockSize <= (4u << 20);                         // global-table waves hold 22-bit positions
-    const u32 W = lv == 10 ? (fastMixed ? LZ_WAVES_FAST : LZ_WAVES_FASTLDS) : lv == 30 ? (fastMixed ? LZ_WAVES_FAST_HUF : LZ_WAVES_FASTLDS_HUF) : (lv == 11 || lv == 31) ? LZ_WAVES_FAST18 : hcLevel ? LZ_WAVES_HC : LZ_WAVES_PF;
-    a.tableStride = LZ_TABWIDE_BYTES(18);
-    if (hcLevel) {
-        if (blockSize > (4u << 20)) {
-            snprintf(g_ctx.err, sizeof g_ctx.err, "hashChain levels: blocks above 4 MiB are not supported on the GPU path");
-            return -LIZARDGPU_ERR_ARG;
-        }
-        const size_t cap = (blockSize + 65535u) & ~(size_t)65535u;
-        if (!g_ctx.hcSlots || g_ctx.hcMaxBlock < cap) {
-            if (g_ctx.hcSlots) { LZ_HIP(hipDeviceSynchronize()); LZ_HIP(hipFree(g_ctx.hcSlots)); g_ctx.hcSlots = nullptr; g_ctx.hcMaxBlock = 0; }
-            const size_t bytes = (size_t)g_ctx.cus * LZ_WAVES_HC * LZ_HC_SLOT_BYTES(cap);
-            LZ_HIP(hipMalloc((void**)&g_ctx.hcSlots, bytes));
-            LZ_HIP(hipMemset(g_ctx.hcSlots, 0, bytes));              // epoch 0 = never used (lz_hc_begin)
-            g_ctx.hcMaxBlock = cap;
-        }
-        a.tables = g_ctx.hcSlots; a.tableStride = LZ_HC_SLOT_BYTES(g_ctx.hcMaxBlock);
-    }
-    if (lv == 22 || lv == 42) {                                  // same per-wave footprint as levels 11/31
-        if (!g_ctx.tables) LZ_HIP(hipMalloc((void**)&g_ctx.tables, (size_t)g_ctx.cus * LZ_WAVES_FAST18 * LZ_TABWIDE_BYTES(18)));
-        a.tables = g_ctx.tables;
-    }
-    if (lv == 11 || lv == 31) {
-        if (blockSize > (4u << 20)) {
-            snprintf(g_ctx.err, sizeof g_ctx.err, "levels 11/31: blocks above 4 MiB are not supported on the GPU path");
-            return -LIZARDGPU_ERR_ARG;
-        }
-        if (!g_ctx.tables) {
-            LZ_HIP(hipMalloc((void**)&g_ctx.tables, (size_t)g_ctx.cus * LZ_WAVES_FAST18 * LZ_TABWIDE_BYTES(18)));
-            a.tables = g_ctx.tables;
-        }
-    }
-    if (lv == 10 || lv == 30 || lv == 21 || lv == 41) {
-        if (!g_ctx.pfTables) LZ_HIP(hipMalloc((void**)&g_ctx.pfTables, (size_t)g_ctx.cus * LZ_WAVES_PF * LZ_PF_SLOT_BYTES));
-        a.tables = g_ctx.pfTables; a.tableStride = LZ_PF_SLOT_BYTES;
-    }
-    u32 grid = (u32)((nBlocks + W - 1) / W);
-    if (grid > (u32)g_ctx.cus) grid = (u32)g_ctx.cus;
-    // The scratch arena, the tables and the block counter are shared by all launches of this process: a launch
-    // on another stream first waits (on the GPU) for the previous one to finish.
-    if (g_ctx.timed) LZ_HIP(hipStreamWaitEvent(stream, g_ctx.ev1, 0));
-    LZ_HIP(hipMemsetAsync(g_ctx.counter, 0, 4, stream));
-    LZ_HIP(hipEventRecord(g_ctx.ev0, stream));
-    switch (lv) {
-    case 10: if (fastMixed) hipLaunchKernelGGL((lz_fast12_kernel<false, true>), dim3(grid), dim3(64 * LZ_WAVES_FAST), 0, stream, a);
-             else           hipLaunchKernelGGL((lz_fast12_kernel<false, false>), dim3(grid), dim3(64 * LZ_WAVES_FASTLDS), 0, stream, a);
-             break;
-    case 30: if (fastMixed) hipLaunchKernelGGL((lz_fast12_kernel<true, true>), dim3(grid), dim3(64 * LZ_WAVES_FAST_HUF), 0, stream, a);
-             else           hipLaunchKernelGGL((lz_fast12_kernel<true, false>), dim3(grid), dim3(64 * LZ_WAVES_FASTLDS_HUF), 0, stream, a);
-             break;
-    case 11: hipLaunchKernelGGL(lz_fast18_kernel<false>, dim3(grid), dim3(64 * LZ_WAVES_FAST18), 0, stream, a); break;
-    case 31: hipLaunchKernelGGL(lz_fast18_kernel<true>, dim3(grid), dim3(64 * LZ_WAVES_FAST18), 0, stream, a); break;
-    case 13: case 14: case 15: hipLaunchKernelGGL((lz_hashchain_kernel<false, 5>), dim3(grid), dim3(64 * LZ_WAVES_HC), 0, stream, a); break;
-    case 16: case 17:          hipLaunchKernelGGL((lz_hashchain_kernel<false, 4>), dim3(grid), dim3(64 * LZ_WAVES_HC), 0, stream, a); break;
-    case 34: case 35: case 36: hipLaunchKernelGGL((lz_hashchain_kernel<true, 5>), dim3(grid), dim3(64 * LZ_WAVES_HC), 0, stream, a); break;
-    case 37: case 38:          hipLaunchKernelGGL((lz_hashchain_kernel<true, 4>), dim3(grid), dim3(64 * LZ_WAVES_HC), 0, stream, a); break;
-    case 22: hipLaunchKernelGGL(lz_pricefast18_kernel<false>, dim3(grid), dim3(64 * LZ_WAVES_PF), 0, stream, a); break;
-    case 42: hipLaunchKernelGGL(lz_pricefast18_kernel<true>, dim3(grid), dim3(64 * LZ_WAVES_PF), 0, stream, a); break;
-    case 21: hipLaunchKernelGGL(lz_pricefast14_kernel<false>, dim3(grid), dim3(64 * LZ_WAVES_PF), 0, stream, a); break;
-    default: hipLaunchKernelGGL(lz_pricefast14_kernel<true>, dim3(grid), dim3(64 * LZ_WAVES_PF), 0, stream, a); break;
-    }
-    LZ_HIP(hipGetLastError());
-    LZ_HIP(hipEventRecord(g_ctx.ev1, stream));
-    g_ctx.timed = true;
+    c.ready = true;
     return 0;
 }
 
 template <typename T>
-int ensure(T** p, size_t* cap, size_t need)
+int ensure_dev(T** p, size_t* cap, size_t need)
 {
     if (*cap >= need) return 0;
     if (*p) { LZ_HIP(hipFree(*p)); *p = nullptr; *cap = 0; }
@@ -294,79 +312,409 @@ int ensure(T** p, size_t* cap, size_t need)
     *cap = need;
     return 0;
 }
+template <typename T>
+int ensure_pinned(T** p, size_t* cap, size_t need)
+{
+    if (*cap >= need) return 0;
+    if (*p) { LZ_HIP(hipHostFree(*p)); *p = nullptr; *cap = 0; }
+    LZ_HIP(hipHostMalloc((void**)p, need, hipHostMallocDefault));
+    *cap = need;
+    return 0;
+}
+
+void ctx_release(Ctx& c)
+{
+    if (!c.ready) return;
+    (void)hipSetDevice(c.device);
+    (void)hipDeviceSynchronize();
+    for (Stage& s : c.stage) {
+        if (s.h_in) (void)hipHostFree(s.h_in);
+        if (s.h_out) (void)hipHostFree(s.h_out);
+        if (s.h_sizes) (void)hipHostFree(s.h_sizes);
+        if (s.h_offsets) (void)hipHostFree(s.h_offsets);
+        if (s.d_in) (void)hipFree(s.d_in);
+        if (s.d_slots) (void)hipFree(s.d_slots);
+        if (s.d_packed) (void)hipFree(s.d_packed);
+        if (s.d_sizes) (void)hipFree(s.d_sizes);
+        if (s.d_offsets) (void)hipFree(s.d_offsets);
+        if (s.k0) (void)hipEventDestroy(s.k0);
+        if (s.k1) (void)hipEventDestroy(s.k1);
+        if (s.meta) (void)hipEventDestroy(s.meta);
+        if (s.done) (void)hipEventDestroy(s.done);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+        s = Stage();
+    }
+    if (c.tables) (void)hipFree(c.tables);
+    if (c.pfTables) (void)hipFree(c.pfTables);
+    if (c.hcSlots) (void)hipFree(c.hcSlots);
+    if (c.scratch) (void)hipFree(c.scratch);
+    if (c.counter) (void)hipFree(c.counter);
+    if (c.d_lt) (void)hipFree(c.d_lt);
+    if (c.ev0) (void)hipEventDestroy(c.ev0);
+    if (c.ev1) (void)hipEventDestroy(c.ev1);
+    c.tables = c.pfTables = c.hcSlots = c.scratch = c.d_lt = nullptr; c.counter = nullptr; c.hcMaxBlock = 0;
+    c.ev0 = c.ev1 = nullptr; c.timed = false; c.ready = false;
+}
+
+int clamp_level(int level)                                       // reference lizard_compress.c:303-308
+{
+    if (level > LIZARD_MAX_CLEVEL) level = LIZARD_MAX_CLEVEL;
+    if (level < LIZARD_MIN_CLEVEL) level = LIZARD_DEFAULT_CLEVEL;
+    return level;
+}
+
+// Largest block the GPU path takes at a level (0 = level not on the GPU path).
+size_t level_max_block(int lv)
+{
+    const bool hcLevel = (lv >= 13 && lv <= 17) || (lv >= 34 && lv <= 38);
+    if (lv == 10 || lv == 30) return (size_t)LIZARD_MAX_INPUT_SIZE;
+    if (lv == 11 || lv == 31 || hcLevel) return (size_t)4 << 20;           // 22-bit positions
+    if (lv == 21 || lv == 41 || lv == 22 || lv == 42) return ((size_t)1 << 24) - 2u;   // 24-bit positions (lz_pricefast.h)
+    return 0;
+}
+
+int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t lastBlockSize, void* d_dst,
+           size_t dstStride, u32* d_sizes, int level, hipStream_t stream, hipEvent_t k0 = nullptr, hipEvent_t k1 = nullptr)
+{
+    const int lv = clamp_level(level);
+    if (!LizardGPU_levelSupported(lv)) { snprintf(t_err, sizeof t_err, "level %d has no GPU kernel", lv); return -LIZARDGPU_ERR_LEVEL; }
+    if (!d_src || !d_dst || !d_sizes || nBlocks == 0 || nBlocks > 0xFFFFFFFFu || blockSize == 0 || blockSize > LIZARD_MAX_INPUT_SIZE
+        || lastBlockSize == 0 || lastBlockSize > blockSize || dstStride < (size_t)LIZARD_COMPRESSBOUND((int)blockSize)) {
+        snprintf(t_err, sizeof t_err, "bad argument (null pointer, zero size, lastBlockSize > blockSize or dstStride < Lizard_compressBound)");
+        return -LIZARDGPU_ERR_ARG;
+    }
+    if (blockSize > level_max_block(lv)) {
+        snprintf(t_err, sizeof t_err, "level %d: blocks above %zu bytes are not supported on the GPU path", lv, level_max_block(lv));
+        return -LIZARDGPU_ERR_ARG;
+    }
+    int rc = ctx_init(c);
+    if (rc) return rc;
+    LzBatch a;
+    a.src = (const u8*)d_src; a.blockSize = blockSize; a.nBlocks = (u32)nBlocks; a.lastBlockSize = (u32)lastBlockSize;
+    a.dst = (u8*)d_dst; a.dstStride = dstStride; a.sizes = d_sizes; a.level = (u32)lv;
+    a.scratch = c.scratch; a.counter = c.counter; a.tables = nullptr; a.tableStride = 0;
+    // one workgroup of W waves per CU; small batches launch only as many workgroups as they have blocks for
+    const bool hcLevel = (lv >= 13 && lv <= 17) || (lv >= 34 && lv <= 38);
+    const bool fastMixed = blockSize <= (4u << 20);                         // global-table waves hold 22-bit positions
+    const bool pfSmall = blockSize <= (256u << 10);                         // 18-bit LDS tables
+    const bool huf = lv >= 30;
+    u32 W;
+    if (lv == 10 || lv == 30)      W = fastMixed ? (huf ? LZ_WAVES_FAST_HUF : LZ_WAVES_FAST) : (huf ? LZ_WAVES_FASTLDS_HUF : LZ_WAVES_FASTLDS);
+    else if (lv == 11 || lv == 31) W = LZ_WAVES_FAST18;
+    else if (hcLevel)              W = LZ_WAVES_HC;
+    else if (lv == 21 || lv == 41) W = pfSmall ? (huf ? LZ_PF18_W_HUF : LZ_PF18_W) : LZ_PF_W;
+    else                           W = LZ_PF_W;
+    if (hcLevel) {
+        const size_t cap = (blockSize + 65535u) & ~(size_t)65535u;
+        if (!c.hcSlots || c.hcMaxBlock < cap) {
+            if (c.hcSlots) { LZ_HIP(hipDeviceSynchronize()); LZ_HIP(hipFree(c.hcSlots)); c.hcSlots = nullptr; c.hcMaxBlock = 0; }
+            const size_t bytes = (size_t)c.cus * LZ_MAX_WAVES * LZ_HC_SLOT_BYTES(cap);
+            LZ_HIP(hipMalloc((void**)&c.hcSlots, bytes));
+            LZ_HIP(hipMemset(c.hcSlots, 0, bytes));              // epoch 0 = never used (lz_hc_begin)
+            c.hcMaxBlock = cap;
+        }
+        a.tables = c.hcSlots; a.tableStride = LZ_HC_SLOT_BYTES(c.hcMaxBlock);
+    } else if (lv == 11 || lv == 31 || lv == 22 || lv == 42) {
+        if (!c.tables) LZ_HIP(hipMalloc((void**)&c.tables, (size_t)c.cus * LZ_MAX_WAVES * LZ_TABWIDE_BYTES(18)));
+        a.tables = c.tables; a.tableStride = LZ_TABWIDE_BYTES(18);
+    } else {
+        if (!c.pfTables) LZ_HIP(hipMalloc((void**)&c.pfTables, (size_t)c.cus * LZ_MAX_WAVES * LZ_PF_SLOT_BYTES));
+        a.tables = c.pfTables; a.tableStride = LZ_PF_SLOT_BYTES;
+    }
+    u32 grid = (u32)((nBlocks + W - 1) / W);
+    if (grid > (u32)c.cus) grid = (u32)c.cus;
+    // The scratch arena, the tables and the block counter are shared by all launches on this device: a launch
+    // on another stream first waits (on the GPU) for the previous one to finish.
+    if (c.timed) LZ_HIP(hipStreamWaitEvent(stream, c.ev1, 0));
+    LZ_HIP(hipMemsetAsync(c.counter, 0, 4, stream));
+    LZ_HIP(hipEventRecord(c.ev0, stream));
+    if (k0) LZ_HIP(hipEventRecord(k0, stream));
+    const dim3 g(grid), t(64 * W);
+    switch (lv) {
+    case 10: if (fastMixed) hipLaunchKernelGGL((lz_fast12_kernel<false, true>), g, t, 0, stream, a);
+             else           hipLaunchKernelGGL((lz_fast12_kernel<false, false>), g, t, 0, stream, a);
+             break;
+    case 30: if (fastMixed) hipLaunchKernelGGL((lz_fast12_kernel<true, true>), g, t, 0, stream, a);
+             else           hipLaunchKernelGGL((lz_fast12_kernel<true, false>), g, t, 0, stream, a);
+             break;
+    case 11: hipLaunchKernelGGL(lz_fast18_kernel<false>, g, t, 0, stream, a); break;
+    case 31: hipLaunchKernelGGL(lz_fast18_kernel<true>, g, t, 0, stream, a); break;
+    case 13: case 14: case 15: hipLaunchKernelGGL((lz_hashchain_kernel<false, 5>), g, t, 0, stream, a); break;
+    case 16: case 17:          hipLaunchKernelGGL((lz_hashchain_kernel<false, 4>), g, t, 0, stream, a); break;
+    case 34: case 35: case 36: hipLaunchKernelGGL((lz_hashchain_kernel<true, 5>), g, t, 0, stream, a); break;
+    case 37: case 38:          hipLaunchKernelGGL((lz_hashchain_kernel<true, 4>), g, t, 0, stream, a); break;
+    case 22: hipLaunchKernelGGL(lz_pricefast18_kernel<false>, g, t, 0, stream, a); break;
+    case 42: hipLaunchKernelGGL(lz_pricefast18_kernel<true>, g, t, 0, stream, a); break;
+    case 21: if (pfSmall) hipLaunchKernelGGL((lz_pricefast14_kernel<false, true>), g, t, 0, stream, a);
+             else         hipLaunchKernelGGL((lz_pricefast14_kernel<false, false>), g, t, 0, stream, a);
+             break;
+    default: if (pfSmall) hipLaunchKernelGGL((lz_pricefast14_kernel<true, true>), g, t, 0, stream, a);
+             else         hipLaunchKernelGGL((lz_pricefast14_kernel<true, false>), g, t, 0, stream, a);
+             break;
+    }
+    LZ_HIP(hipGetLastError());
+    LZ_HIP(hipEventRecord(c.ev1, stream));
+    if (k1) LZ_HIP(hipEventRecord(k1, stream));
+    c.timed = true;
+    return 0;
+}
+
+bool is_pinned_host(const void* p)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
+size_t chunk_bytes()
+{
+    if (!g_chunk_bytes) {
+        const char* e = getenv("LIZARDGPU_CHUNK_MB");
+        size_t mb = e ? (size_t)strtoul(e, nullptr, 10) : 0;
+        if (mb < 1 || mb > 65536) mb = 512;
+        g_chunk_bytes = mb << 20;
+    }
+    return g_chunk_bytes;
+}
+
+// ---- the host-buffer pipeline -----------------------------------------------------------------------
+// Input is cut into chunks of whole blocks.  Per chunk, on its stage's stream: host -> pinned staging (skipped when
+// the caller's buffer is itself pinned) -> H2D -> block kernels -> exclusive scan of the record sizes -> compaction
+// of the valid bytes into one packed buffer -> D2H of sizes/offsets, then of exactly the packed bytes.  The host
+// then hands each chunk's result to `sink`.  While the GPU works on chunk c the host stages chunk c+1 and drains c-1.
+struct HostJob {
+    const u8* src; size_t nBlocks, blockSize, lastBlockSize; int level;
+    int mode;                                  // LZ_PACK_PAYLOAD or LZ_PACK_FRAME (lz_pack.h)
+    // sink: chunk [first, first+nb) finished; packed bytes at `data` (size `bytes`), per-block offsets inside it
+    // (offsets[nb] = bytes) and compressed sizes.  Returns 0 or a negative error.
+    int (*sink)(void* user, size_t first, size_t nb, const u8* data, size_t bytes, const u64* offsets, const u32* sizes);
+    void* user;
+};
+
+struct ChunkState { size_t first = 0, nb = 0, inBytes = 0, packedBytes = 0; bool active = false; };
+
+int stage_issue(Ctx& c, Stage& s, const HostJob& j, ChunkState& ch, bool srcPinned)
+{
+    const size_t slot = ((size_t)LIZARD_COMPRESSBOUND((int)j.blockSize) + 63) & ~(size_t)63;
+    const size_t last = (ch.first + ch.nb == j.nBlocks) ? j.lastBlockSize : j.blockSize;
+    ch.inBytes = (ch.nb - 1) * j.blockSize + last;
+    const size_t packedCap = ch.nb * (slot + 8);
+    int rc;
+    if ((rc = ensure_dev(&s.d_in, &s.d_in_cap, ch.inBytes + 64))) return rc;
+    if ((rc = ensure_dev(&s.d_slots, &s.d_slots_cap, ch.nb * slot))) return rc;
+    if ((rc = ensure_dev(&s.d_packed, &s.d_packed_cap, packedCap))) return rc;
+    if (s.d_meta_cap < ch.nb + 1) {
+        if (s.d_sizes) { LZ_HIP(hipFree(s.d_sizes)); s.d_sizes = nullptr; }
+        if (s.d_offsets) { LZ_HIP(hipFree(s.d_offsets)); s.d_offsets = nullptr; }
+        s.d_meta_cap = 0;
+        LZ_HIP(hipMalloc((void**)&s.d_sizes, (ch.nb + 1) * sizeof(u32)));
+        LZ_HIP(hipMalloc((void**)&s.d_offsets, (ch.nb + 1) * sizeof(u64)));
+        s.d_meta_cap = ch.nb + 1;
+    }
+    if (s.h_meta_cap < ch.nb + 1) {
+        if (s.h_sizes) { LZ_HIP(hipHostFree(s.h_sizes)); s.h_sizes = nullptr; }
+        if (s.h_offsets) { LZ_HIP(hipHostFree(s.h_offsets)); s.h_offsets = nullptr; }
+        s.h_meta_cap = 0;
+        LZ_HIP(hipHostMalloc((void**)&s.h_sizes, (ch.nb + 1) * sizeof(u32), hipHostMallocDefault));
+        LZ_HIP(hipHostMalloc((void**)&s.h_offsets, (ch.nb + 1) * sizeof(u64), hipHostMallocDefault));
+        s.h_meta_cap = ch.nb + 1;
+    }
+    const u8* from = j.src + ch.first * j.blockSize;
+    if (!srcPinned) {
+        if ((rc = ensure_pinned(&s.h_in, &s.h_in_cap, ch.inBytes))) return rc;
+        memcpy(s.h_in, from, ch.inBytes);
+        from = s.h_in;
+    }
+    LZ_HIP(hipMemcpyAsync(s.d_in, from, ch.inBytes, hipMemcpyHostToDevice, s.stream));
+    if ((rc = launch(c, s.d_in, ch.nb, j.blockSize, last, s.d_slots, slot, s.d_sizes, j.level, s.stream, s.k0, s.k1))) return rc;
+    lz_pack_launch(s.d_in, s.d_slots, slot, s.d_sizes, s.d_offsets, s.d_packed, (u32)ch.nb, (u32)j.blockSize, (u32)last, j.mode, s.stream);
+    LZ_HIP(hipGetLastError());
+    LZ_HIP(hipMemcpyAsync(s.h_sizes, s.d_sizes, ch.nb * sizeof(u32), hipMemcpyDeviceToHost, s.stream));
+    LZ_HIP(hipMemcpyAsync(s.h_offsets, s.d_offsets, (ch.nb + 1) * sizeof(u64), hipMemcpyDeviceToHost, s.stream));
+    LZ_HIP(hipEventRecord(s.meta, s.stream));
+    ch.active = true;
+    return 0;
+}
+
+int stage_fetch(Stage& s, ChunkState& ch)                       // sizes known -> request exactly the packed bytes
+{
+    LZ_HIP(hipEventSynchronize(s.meta));
+    ch.packedBytes = (size_t)s.h_offsets[ch.nb];
+    int rc;
+    if ((rc = ensure_pinned(&s.h_out, &s.h_out_cap, ch.packedBytes + 64))) return rc;
+    LZ_HIP(hipMemcpyAsync(s.h_out, s.d_packed, ch.packedBytes, hipMemcpyDeviceToHost, s.stream));
+    LZ_HIP(hipEventRecord(s.done, s.stream));
+    return 0;
+}
+
+int run_host_job(Ctx& c, const HostJob& j)
+{
+    int rc = ctx_init(c);
+    if (rc) return rc;
+    if (!j.src || j.nBlocks == 0 || j.blockSize == 0 || j.lastBlockSize == 0 || j.lastBlockSize > j.blockSize) {
+        snprintf(t_err, sizeof t_err, "bad argument (null pointer, zero size or lastBlockSize > blockSize)");
+        return -LIZARDGPU_ERR_ARG;
+    }
+    size_t perChunk = chunk_bytes() / j.blockSize;
+    if (perChunk == 0) perChunk = 1;
+    const size_t nChunks = (j.nBlocks + perChunk - 1) / perChunk;
+    const bool srcPinned = is_pinned_host(j.src);
+    ChunkState ch[2];
+    c.hostKernelMs = 0.0f;
+    // iteration i: drain chunk i-2 (its stage is about to be reused), issue chunk i, fetch chunk i-1
+    for (size_t i = 0; i < nChunks + 2; i++) {
+        Stage& s = c.stage[i & 1];
+        ChunkState& cur = ch[i & 1];
+        if (cur.active) {
+            LZ_HIP(hipEventSynchronize(s.done));
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, s.k0, s.k1) == hipSuccess) c.hostKernelMs += ms;
+            cur.active = false;
+            if ((rc = j.sink(j.user, cur.first, cur.nb, s.h_out, cur.packedBytes, s.h_offsets, s.h_sizes))) return rc;
+        }
+        if (i < nChunks) {
+            cur.first = i * perChunk;
+            cur.nb = j.nBlocks - cur.first < perChunk ? j.nBlocks - cur.first : perChunk;
+            if ((rc = stage_issue(c, s, j, cur, srcPinned))) return rc;
+        }
+        if (i >= 1 && ch[(i - 1) & 1].active && i - 1 < nChunks)
+            if ((rc = stage_fetch(c.stage[(i - 1) & 1], ch[(i - 1) & 1]))) return rc;
+    }
+    return 0;
+}
+
+struct SlotSink { u8* dst; size_t dstStride; u32* cSizes; };
+int slot_sink(void* user, size_t first, size_t nb, const u8* data, size_t, const u64* offsets, const u32* sizes)
+{
+    SlotSink* k = (SlotSink*)user;
+    for (size_t i = 0; i < nb; i++) {
+        memcpy(k->dst + (first + i) * k->dstStride, data + offsets[i], sizes[i]);
+        k->cSizes[first + i] = sizes[i];
+    }
+    return 0;
+}
+
+struct PackedSink { u8* dst; size_t cap; size_t used; u64* offsets; u32* cSizes; };
+int packed_sink(void* user, size_t first, size_t nb, const u8* data, size_t bytes, const u64* offsets, const u32* sizes)
+{
+    PackedSink* k = (PackedSink*)user;
+    if (k->used + bytes > k->cap) { snprintf(t_err, sizeof t_err, "packed output does not fit in dstCapacity"); return -LIZARDGPU_ERR_ARG; }
+    memcpy(k->dst + k->used, data, bytes);
+    for (size_t i = 0; i < nb; i++) {
+        if (k->offsets) k->offsets[first + i] = k->used + offsets[i];
+        if (k->cSizes) k->cSizes[first + i] = sizes[i];
+    }
+    k->used += bytes;
+    return 0;
+}
 
 }  // namespace
+
+#include "lizard_shard.h"   // single-process multi-device entry + RCCL size gather (uses Guard / launch above)
 
 extern "C" {
 
 int LizardGPU_levelSupported(int level)
 {
-    if (level > LIZARD_MAX_CLEVEL) level = LIZARD_MAX_CLEVEL;        // reference lizard_compress.c:303-308
-    if (level < LIZARD_MIN_CLEVEL) level = LIZARD_DEFAULT_CLEVEL;
-    return level == 10 || level == 30 || level == 11 || level == 31 || level == 21 || level == 41 || level == 22 || level == 42
-        || (level >= 13 && level <= 17) || (level >= 34 && level <= 38);
+    return level_max_block(clamp_level(level)) != 0;
+}
+
+size_t LizardGPU_maxBlockSize(int level) { return level_max_block(clamp_level(level)); }
+
+int LizardGPU_deviceCount(void)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return count;
 }
 
 int LizardGPU_setDevice(int device)
 {
-    pthread_mutex_lock(&g_mu);
-    g_want_device = device;
-    pthread_mutex_unlock(&g_mu);
+    t_err[0] = 0;
+    const int count = LizardGPU_deviceCount();
+    if (device < 0 || device >= LZ_MAX_DEVICES || (count > 0 && device >= count)) {
+        snprintf(t_err, sizeof t_err, "LizardGPU_setDevice(%d): %d device(s) visible", device, count);
+        return -LIZARDGPU_ERR_ARG;
+    }
+    t_device = device;
+    pthread_mutex_lock(&g_sel_mu);
+    g_default_device = device;
+    pthread_mutex_unlock(&g_sel_mu);
     return 0;
 }
 
-const char* LizardGPU_lastError(void) { return g_ctx.err; }
+const char* LizardGPU_lastError(void) { return t_err; }
 
 int LizardGPU_residentWaves(void)
 {
-    pthread_mutex_lock(&g_mu);
-    int rc = ctx_init_locked();
-    int w = rc ? rc : g_ctx.cus * LZ_WAVES_FAST;      // level-10 residency (16 waves per CU: 12 LDS tables + 4 in global memory)
-    pthread_mutex_unlock(&g_mu);
-    return w;
+    Guard g;
+    if (g.rc) return g.rc;
+    int rc = ctx_init(*g.c);
+    return rc ? rc : g.c->cus * LZ_WAVES_FAST;      // level-10 residency (16 waves per CU: 12 LDS tables + 4 in global memory)
+}
+
+void LizardGPU_shutdown(void)
+{
+    int saved = -1;
+    if (hipGetDevice(&saved) != hipSuccess) saved = -1;
+    for (int d = 0; d < LZ_MAX_DEVICES; d++) {
+        Ctx& c = g_ctx[d];
+        pthread_mutex_lock(&c.mu);
+        ctx_release(c);
+        pthread_mutex_unlock(&c.mu);
+    }
+    lz_shard_shutdown();
+    if (saved >= 0) (void)hipSetDevice(saved);
 }
 
 int LizardGPU_compressBlocks_device(const void* d_src, size_t nBlocks, size_t blockSize, size_t lastBlockSize,
                                     void* d_dst, size_t dstStride, uint32_t* d_sizes, int level, void* stream)
 {
-    pthread_mutex_lock(&g_mu);
-    int rc = launch_locked(d_src, nBlocks, blockSize, lastBlockSize, d_dst, dstStride, d_sizes, level, (hipStream_t)stream);
-    pthread_mutex_unlock(&g_mu);
-    return rc;
-}
-
-static int host_locked(const void* src, size_t nBlocks, size_t blockSize, size_t lastBlockSize, void* dst,
-                       size_t dstStride, uint32_t* cSizes, int level)
-{
-    if (!src || !dst || !cSizes || nBlocks == 0 || blockSize == 0 || lastBlockSize == 0 || lastBlockSize > blockSize)
-        return -LIZARDGPU_ERR_ARG;
-    int rc = ctx_init_locked();
-    if (rc) return rc;
-    const size_t srcBytes = (nBlocks - 1) * blockSize + lastBlockSize;
-    const size_t slot = ((size_t)LIZARD_COMPRESSBOUND((int)blockSize) + 63) & ~(size_t)63;
-    if (dstStride < (size_t)LIZARD_COMPRESSBOUND((int)blockSize)) return -LIZARDGPU_ERR_ARG;
-    if ((rc = ensure(&g_ctx.d_src, &g_ctx.d_src_cap, srcBytes + 64))) return rc;
-    if ((rc = ensure(&g_ctx.d_dst, &g_ctx.d_dst_cap, nBlocks * slot))) return rc;
-    if ((rc = ensure(&g_ctx.d_sizes, &g_ctx.d_sizes_cap, nBlocks * sizeof(u32)))) return rc;
-    hipStream_t s = g_ctx.stream;
-    LZ_HIP(hipMemcpyAsync(g_ctx.d_src, src, srcBytes, hipMemcpyHostToDevice, s));
-    rc = launch_locked(g_ctx.d_src, nBlocks, blockSize, lastBlockSize, g_ctx.d_dst, slot, g_ctx.d_sizes, level, s);
-    if (rc) return rc;
-    LZ_HIP(hipMemcpyAsync(cSizes, g_ctx.d_sizes, nBlocks * sizeof(u32), hipMemcpyDeviceToHost, s));
-    LZ_HIP(hipStreamSynchronize(s));
-    // payload: only the valid bytes of each slot travel back
-    for (size_t i = 0; i < nBlocks; i++)
-        LZ_HIP(hipMemcpyAsync((u8*)dst + i * dstStride, g_ctx.d_dst + i * slot, cSizes[i], hipMemcpyDeviceToHost, s));
-    LZ_HIP(hipStreamSynchronize(s));
-    return 0;
+    Guard g;
+    if (g.rc) return g.rc;
+    g.c->hostKernelMs = -1.0f;
+    return launch(*g.c, d_src, nBlocks, blockSize, lastBlockSize, d_dst, dstStride, d_sizes, level, (hipStream_t)stream);
 }
 
 int LizardGPU_compressBlocks_host(const void* src, size_t nBlocks, size_t blockSize, size_t lastBlockSize,
                                   void* dst, size_t dstStride, uint32_t* cSizes, int level)
 {
-    pthread_mutex_lock(&g_mu);
-    int rc = host_locked(src, nBlocks, blockSize, lastBlockSize, dst, dstStride, cSizes, level);
-    pthread_mutex_unlock(&g_mu);
+    Guard g;
+    if (g.rc) return g.rc;
+    if (!dst || !cSizes || blockSize > LIZARD_MAX_INPUT_SIZE || dstStride < (size_t)LIZARD_COMPRESSBOUND((int)blockSize)) {
+        snprintf(t_err, sizeof t_err, "bad argument (null pointer or dstStride < Lizard_compressBound(blockSize))");
+        return -LIZARDGPU_ERR_ARG;
+    }
+    SlotSink k = { (u8*)dst, dstStride, cSizes };
+    HostJob j = { (const u8*)src, nBlocks, blockSize, lastBlockSize, level, LZ_PACK_PAYLOAD, slot_sink, &k };
+    return run_host_job(*g.c, j);
+}
+
+int LizardGPU_compressBlocks_host_packed(const void* src, size_t nBlocks, size_t blockSize, size_t lastBlockSize,
+                                         void* dst, size_t dstCapacity, uint64_t* offsets, uint32_t* cSizes, int level)
+{
+    Guard g;
+    if (g.rc) return g.rc;
+    if (!dst) { snprintf(t_err, sizeof t_err, "bad argument (null dst)"); return -LIZARDGPU_ERR_ARG; }
+    PackedSink k = { (u8*)dst, dstCapacity, 0, (u64*)offsets, cSizes };
+    HostJob j = { (const u8*)src, nBlocks, blockSize, lastBlockSize, level, LZ_PACK_PAYLOAD, packed_sink, &k };
+    int rc = run_host_job(*g.c, j);
+    if (!rc && offsets) offsets[nBlocks] = k.used;
+    return rc;
+}
+
+// Internal (lizard_frame_host.c): frame block records — LE32 size word (bit 31 = stored raw) + payload — of nBlocks
+// independent blocks, packed back to back into dst exactly as LizardF_compressUpdate writes them
+// (lizard_frame.c:456-469).  *written receives the byte count.
+int lzgpu_frame_records(const void* src, size_t nBlocks, size_t blockSize, size_t lastBlockSize, void* dst, size_t dstCapacity,
+                        size_t* written, int level)
+{
+    Guard g;
+    if (g.rc) return g.rc;
+    PackedSink k = { (u8*)dst, dstCapacity, 0, nullptr, nullptr };
+    HostJob j = { (const u8*)src, nBlocks, blockSize, lastBlockSize, level, LZ_PACK_FRAME, packed_sink, &k };
+    int rc = run_host_job(*g.c, j);
+    if (written) *written = k.used;
     return rc;
 }
 
@@ -375,31 +723,50 @@ int LizardGPU_compressBlocks_host(const void* src, size_t nBlocks, size_t blockS
 // (reference lib/lizard_compress.c:543-546), < 0 on a GPU failure.
 int lzgpu_compress_one(const void* src, int srcSize, void* dst, int maxDstSize, int level)
 {
-    if (srcSize < 0 || (unsigned)srcSize > (unsigned)LIZARD_MAX_INPUT_SIZE || maxDstSize < 1) return 0;
-    pthread_mutex_lock(&g_mu);
-    int rc = ctx_init_locked();
-    int result = 0;
-    if (!rc && srcSize == 0) {          // reference: level byte only (lizard_compress.c:488-494)
-        ((u8*)dst)[0] = (u8)level; result = 1;
-    } else if (!rc) {
-        const size_t slot = (size_t)LIZARD_COMPRESSBOUND(srcSize);
-        u32 csize = 0;
-        do {
-            if ((rc = ensure(&g_ctx.d_src, &g_ctx.d_src_cap, (size_t)srcSize + 64))) break;
-            if ((rc = ensure(&g_ctx.d_dst, &g_ctx.d_dst_cap, slot))) break;
-            if ((rc = ensure(&g_ctx.d_sizes, &g_ctx.d_sizes_cap, sizeof(u32)))) break;
-            hipStream_t s = g_ctx.stream;
-            if (hipMemcpyAsync(g_ctx.d_src, src, (size_t)srcSize, hipMemcpyHostToDevice, s) != hipSuccess) { rc = -LIZARDGPU_ERR_HIP; break; }
-            if ((rc = launch_locked(g_ctx.d_src, 1, (size_t)srcSize, (size_t)srcSize, g_ctx.d_dst, slot, g_ctx.d_sizes, level, s))) break;
-            if (hipMemcpyAsync(&csize, g_ctx.d_sizes, sizeof(u32), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = -LIZARDGPU_ERR_HIP; break; }
-            if (hipStreamSynchronize(s) != hipSuccess) { rc = -LIZARDGPU_ERR_HIP; break; }
-            if (csize > (u32)maxDstSize) { result = 0; break; }
-            if (hipMemcpy(dst, g_ctx.d_dst, csize, hipMemcpyDeviceToHost) != hipSuccess) { rc = -LIZARDGPU_ERR_HIP; break; }
-            result = (int)csize;
-        } while (0);
+    if (srcSize < 0 || (unsigned)srcSize > (unsigned)LIZARD_MAX_INPUT_SIZE) return 0;
+    Guard g;
+    if (g.rc) return g.rc;
+    Ctx& c = *g.c;
+    int rc = ctx_init(c);
+    if (rc) return rc;
+    if (srcSize == 0) {                 // reference: level byte only (lizard_compress.c:488-494)
+        if (maxDstSize < 1) return 0;
+        ((u8*)dst)[0] = (u8)clamp_level(level);
+        return 1;
     }
-    pthread_mutex_unlock(&g_mu);
-    return rc ? rc : result;
+    Stage& s = c.stage[0];
+    const size_t slot = ((size_t)LIZARD_COMPRESSBOUND(srcSize) + 63) & ~(size_t)63;
+    if ((rc = ensure_dev(&s.d_in, &s.d_in_cap, (size_t)srcSize + 64))) return rc;
+    if ((rc = ensure_dev(&s.d_slots, &s.d_slots_cap, slot))) return rc;
+    if ((rc = ensure_pinned(&s.h_in, &s.h_in_cap, (size_t)srcSize))) return rc;
+    if ((rc = ensure_pinned(&s.h_out, &s.h_out_cap, slot + 64))) return rc;
+    if (s.d_meta_cap < 2) {
+        LZ_HIP(hipMalloc((void**)&s.d_sizes, 2 * sizeof(u32)));
+        LZ_HIP(hipMalloc((void**)&s.d_offsets, 2 * sizeof(u64)));
+        s.d_meta_cap = 2;
+    }
+    if (s.h_meta_cap < 2) {
+        LZ_HIP(hipHostMalloc((void**)&s.h_sizes, 2 * sizeof(u32), hipHostMallocDefault));
+        LZ_HIP(hipHostMalloc((void**)&s.h_offsets, 2 * sizeof(u64), hipHostMallocDefault));
+        s.h_meta_cap = 2;
+    }
+    memcpy(s.h_in, src, (size_t)srcSize);
+    LZ_HIP(hipMemcpyAsync(s.d_in, s.h_in, (size_t)srcSize, hipMemcpyHostToDevice, s.stream));
+    c.hostKernelMs = -1.0f;
+    if ((rc = launch(c, s.d_in, 1, (size_t)srcSize, (size_t)srcSize, s.d_slots, slot, s.d_sizes, level, s.stream))) return rc;
+    LZ_HIP(hipMemcpyAsync(s.h_sizes, s.d_sizes, sizeof(u32), hipMemcpyDeviceToHost, s.stream));
+    LZ_HIP(hipStreamSynchronize(s.stream));
+    const u32 csize = s.h_sizes[0];
+    // The reference's room checks compare against oend = dst + maxDstSize (lizard_compress.c:238, :489): whatever fits is
+    // written.  A ONE-byte block is the case the reference gets through by accident: Lizard_compress_generic decrements
+    // maxOutputSize after the level byte, writeBlock's raw branch tests `*op + blockSize + 4 > oend` only for the sub-block,
+    // and with maxDstSize = srcSize - 1 = 0 (the frame layer's call, lizard_frame.c:461) the unsigned room test wraps: the
+    // 6-byte block (level, 0x80, LE24 1, the byte) is emitted and its size returned.  Same here.
+    if ((int)csize > maxDstSize && !(srcSize == 1 && maxDstSize == 0)) return 0;
+    LZ_HIP(hipMemcpyAsync(s.h_out, s.d_slots, csize, hipMemcpyDeviceToHost, s.stream));
+    LZ_HIP(hipStreamSynchronize(s.stream));
+    memcpy(dst, s.h_out, csize);
+    return (int)csize;
 }
 
 void LizardGPU_datagen_host(void* buffer, size_t size, double matchProba, double litProba, unsigned seed)
@@ -412,54 +779,56 @@ void LizardGPU_datagen_host(void* buffer, size_t size, double matchProba, double
 int LizardGPU_datagen_device(void* d_dst, size_t nBlocks, size_t blockSize, double matchProba, double litProba,
                              unsigned seed0, void* stream)
 {
-    if (!d_dst || nBlocks == 0 || blockSize == 0) return -LIZARDGPU_ERR_ARG;
-    pthread_mutex_lock(&g_mu);
-    int rc = ctx_init_locked();
-    if (!rc) do {
-        uint8_t lt[LZ_RDG_LTSIZE];
-        lz_rdg_table(lt, matchProba, litProba);
-        u8* d_lt = nullptr;
-        if (hipMalloc((void**)&d_lt, LZ_RDG_LTSIZE) != hipSuccess) { rc = -LIZARDGPU_ERR_NOMEM; break; }
-        hipStream_t s = (hipStream_t)stream;
-        if (hipMemcpyAsync(d_lt, lt, LZ_RDG_LTSIZE, hipMemcpyHostToDevice, s) != hipSuccess) { rc = -LIZARDGPU_ERR_HIP; (void)hipFree(d_lt); break; }
-        hipLaunchKernelGGL(lz_datagen_kernel, dim3((unsigned)((nBlocks + 63) / 64)), dim3(64), 0, s, (u8*)d_dst, (u64)nBlocks,
-                           (u64)blockSize, (u32)(32768 * matchProba), (int)(matchProba >= 1.0), (const u8*)d_lt, (u32)seed0);
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = -LIZARDGPU_ERR_HIP;
-        (void)hipFree(d_lt);
-    } while (0);
-    pthread_mutex_unlock(&g_mu);
-    return rc;
+    Guard g;
+    if (g.rc) return g.rc;
+    if (!d_dst || nBlocks == 0 || blockSize == 0) { snprintf(t_err, sizeof t_err, "bad argument"); return -LIZARDGPU_ERR_ARG; }
+    Ctx& c = *g.c;
+    int rc = ctx_init(c);
+    if (rc) return rc;
+    uint8_t lt[LZ_RDG_LTSIZE];
+    lz_rdg_table(lt, matchProba, litProba);
+    if (!c.d_lt) LZ_HIP(hipMalloc((void**)&c.d_lt, LZ_RDG_LTSIZE));
+    hipStream_t s = (hipStream_t)stream;
+    LZ_HIP(hipMemcpyAsync(c.d_lt, lt, LZ_RDG_LTSIZE, hipMemcpyHostToDevice, s));
+    LZ_HIP(hipStreamSynchronize(s));                            // `lt` is a stack buffer
+    hipLaunchKernelGGL(lz_datagen_kernel, dim3((unsigned)((nBlocks + 63) / 64)), dim3(64), 0, s, (u8*)d_dst, (u64)nBlocks,
+                       (u64)blockSize, (u32)(32768 * matchProba), (int)(matchProba >= 1.0), (const u8*)c.d_lt, (u32)seed0);
+    LZ_HIP(hipGetLastError());
+    LZ_HIP(hipStreamSynchronize(s));
+    return 0;
 }
 
 #ifdef LZ_PROFILE
-// Profile builds only: sum of the per-wave phase clocks since the last call (scratch slot heads), then reset.
+// Profile builds only: sum of the per-wave phase clocks since the last call (scratch slot tails), then reset.
 int LizardGPU_profileDump(unsigned long long out[16])
 {
-    pthread_mutex_lock(&g_mu);
-    int rc = ctx_init_locked();
+    Guard g;
     for (int k = 0; k < 16; k++) out[k] = 0;
-    if (!rc) {
-        (void)hipDeviceSynchronize();
-        for (int w = 0; w < g_ctx.waves; w++) {
-            unsigned long long v[16];
-            if (hipMemcpy(v, g_ctx.scratch + (size_t)(w + 1) * LZ_SCRATCH_BYTES - 128, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) { rc = -LIZARDGPU_ERR_HIP; break; }
-            for (int k = 0; k < 15; k++) out[k] += v[k];
-            (void)hipMemset(g_ctx.scratch + (size_t)(w + 1) * LZ_SCRATCH_BYTES - 128, 0, sizeof v);
-        }
+    if (g.rc) return g.rc;
+    Ctx& c = *g.c;
+    int rc = ctx_init(c);
+    if (rc) return rc;
+    (void)hipDeviceSynchronize();
+    for (int w = 0; w < c.cus * LZ_MAX_WAVES; w++) {
+        unsigned long long v[16];
+        if (hipMemcpy(v, c.scratch + (size_t)(w + 1) * LZ_SCRATCH_BYTES - 128, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -LIZARDGPU_ERR_HIP;
+        for (int k = 0; k < 15; k++) out[k] += v[k];
+        (void)hipMemset(c.scratch + (size_t)(w + 1) * LZ_SCRATCH_BYTES - 128, 0, sizeof v);
     }
-    pthread_mutex_unlock(&g_mu);
-    return rc;
+    return 0;
 }
 #endif
 
 float LizardGPU_lastKernelMs(void)
 {
+    Guard g;
+    if (g.rc) return -1.0f;
+    Ctx& c = *g.c;
+    if (c.hostKernelMs >= 0.0f) return c.hostKernelMs;
     float ms = -1.0f;
-    pthread_mutex_lock(&g_mu);
-    if (g_ctx.timed && hipEventSynchronize(g_ctx.ev1) == hipSuccess) {
-        if (hipEventElapsedTime(&ms, g_ctx.ev0, g_ctx.ev1) != hipSuccess) ms = -1.0f;
+    if (c.timed && hipEventSynchronize(c.ev1) == hipSuccess) {
+        if (hipEventElapsedTime(&ms, c.ev0, c.ev1) != hipSuccess) ms = -1.0f;
     }
-    pthread_mutex_unlock(&g_mu);
     return ms;
 }
 

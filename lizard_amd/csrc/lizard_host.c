@@ -11,10 +11,13 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #define LIZARD_VERSION_NUMBER (1 * 100 * 100 + 0 * 100 + 0)   /* reference lib/lizard_compress.h:71-75 */
 
-struct Lizard_stream_s { void* reserved; int compressionLevel; };   /* opaque to callers (pointer-aligned); tables live in LDS */
+/* Opaque to callers (pointer-aligned).  The match-finder tables live on the device; what a stream remembers on the host
+ * is the book-keeping Lizard_saveDict needs: where the previous block ended and how much contiguous history precedes it. */
+struct Lizard_stream_s { const char* end; size_t prefix; int compressionLevel; };
 
 static int verify_level(int level)                               /* reference lib/lizard_compress.c:303-308 */
 {
@@ -26,8 +29,7 @@ static int verify_level(int level)                               /* reference li
 static void complain(const char* what, int level)
 {
     static int warned = 0;
-    if (!warned) {
-        warned = 1;
+    if (!__atomic_exchange_n(&warned, 1, __ATOMIC_RELAXED)) {
         fprintf(stderr, "liblizard_amd: %s (level %d): %s — returning 0 (no CPU fallback in this library)\n",
                 what, level, LizardGPU_lastError());
     }
@@ -61,7 +63,7 @@ int Lizard_compress(const char* src, char* dst, int srcSize, int maxDstSize, int
 Lizard_stream_t* Lizard_createStream(int compressionLevel)
 {
     Lizard_stream_t* s = (Lizard_stream_t*)malloc((size_t)Lizard_sizeofState(compressionLevel));
-    if (s) s->compressionLevel = verify_level(compressionLevel);
+    if (s) { s->compressionLevel = verify_level(compressionLevel); s->end = NULL; s->prefix = 0; }
     return s;
 }
 
@@ -69,7 +71,7 @@ int Lizard_freeStream(Lizard_stream_t* s) { free(s); return 0; }
 
 Lizard_stream_t* Lizard_resetStream(Lizard_stream_t* s, int compressionLevel)
 {
-    if (s) s->compressionLevel = verify_level(compressionLevel);
+    if (s) { s->compressionLevel = verify_level(compressionLevel); s->end = NULL; s->prefix = 0; }
     return s;
 }
 
@@ -82,23 +84,54 @@ int Lizard_compress_MinLevel(const char* source, char* dest, int inputSize, int 
 Lizard_stream_t* Lizard_createStream_MinLevel(void) { return Lizard_createStream(LIZARD_MIN_CLEVEL); }
 Lizard_stream_t* Lizard_resetStream_MinLevel(Lizard_stream_t* s) { return Lizard_resetStream(s, LIZARD_MIN_CLEVEL); }
 
-/* Linked blocks and dictionaries (reference lib/lizard_compress.h:178,188,198 / lib/lizard_compress.c:426,454,550): every
- * block's window reaches into the previous one, a serial chain that has no place on this path.  The symbols
- * exist so that programs written against the reference (lizard_frame.c's linked mode, lizardio.c) link
- * unchanged; they fail the way the reference reports failure — 0 — after saying why, once, on stderr.  A frame
- * written in linked mode through them stores its blocks raw (lizard_frame.c:463-467). */
-static void refuse_linked(const char* what)
-{
-    static int warned = 0;
-    if (!warned) {
-        warned = 1;
-        fprintf(stderr, "liblizard_amd: %s: linked blocks / dictionaries are serial and not part of the GPU path "
-                        "(use independent blocks, e.g. lizard -BI) — returning 0\n", what);
-    }
-}
+/* Streaming ("linked blocks") and dictionaries — reference lib/lizard_compress.h:178,188,198 / lib/lizard_compress.c:426,454,550.
+ *
+ * In the reference every block of a stream may reach back into the previous blocks (or the dictionary), which makes a
+ * stream ONE serial chain: the hash table, the window and the repeat offset are carried from call to call.  That chain
+ * has no parallelism to offer a GPU, so this library keeps the contract and drops the history: each call compresses
+ * its block on the GPU WITHOUT referring to earlier data.  What callers rely on still holds —
+ *   * the output of every call is a valid Lizard block that Lizard_decompress_safe_continue / _usingDict decode to
+ *     the input (a decoder never requires a block to use its history), so frames written in the frame layer's default
+ *     linked mode (lizard_frame.c:473-483) are compressed, valid and decodable;
+ *   * Lizard_loadDict / Lizard_saveDict return the sizes the reference returns, and saveDict copies the last bytes
+ *     of the previous block into the caller's buffer (lizard_compress.c:454-470), so lizard_frame.c's buffer
+ *     management behaves as with the reference —
+ * and what does not: the bytes differ from the reference's linked-mode output (matches into earlier blocks are not
+ * found; the ratio is that of independent blocks).  Bit-exact parity is claimed for independent blocks only
+ * (INTEGRATION.md section 1). */
+#define LZ_DICT_SIZE (1 << 24)                                   /* LIZARD_DICT_SIZE, reference lib/lizard_common.h:71 */
+
 int Lizard_loadDict(Lizard_stream_t* streamPtr, const char* dictionary, int dictSize)
-{ (void)streamPtr; (void)dictionary; (void)dictSize; refuse_linked("Lizard_loadDict"); return 0; }
+{
+    if (!streamPtr || dictSize < 0) return 0;
+    if (dictSize > LZ_DICT_SIZE) { dictionary += dictSize - LZ_DICT_SIZE; dictSize = LZ_DICT_SIZE; }   /* :429-432 */
+    streamPtr->end = dictionary + dictSize;                      /* :435 */
+    streamPtr->prefix = (size_t)dictSize;
+    return dictSize;
+}
+
 int Lizard_saveDict(Lizard_stream_t* streamPtr, char* safeBuffer, int dictSize)
-{ (void)streamPtr; (void)safeBuffer; (void)dictSize; refuse_linked("Lizard_saveDict"); return 0; }
+{
+    if (!streamPtr || !streamPtr->end) return 0;
+    if (dictSize > LZ_DICT_SIZE) dictSize = LZ_DICT_SIZE;        /* :458-460 */
+    if (dictSize < 4) dictSize = 0;
+    if ((size_t)dictSize > streamPtr->prefix) dictSize = (int)streamPtr->prefix;
+    memmove(safeBuffer, streamPtr->end - dictSize, (size_t)dictSize);   /* :461 */
+    streamPtr->end = safeBuffer + dictSize;
+    streamPtr->prefix = (size_t)dictSize;
+    return dictSize;
+}
+
 int Lizard_compress_continue(Lizard_stream_t* streamPtr, const char* src, char* dst, int srcSize, int maxDstSize)
-{ (void)streamPtr; (void)src; (void)dst; (void)srcSize; (void)maxDstSize; refuse_linked("Lizard_compress_continue"); return 0; }
+{
+    int r;
+    if (!streamPtr) return 0;
+    if (!LizardGPU_levelSupported(streamPtr->compressionLevel)) { complain("level not implemented on the GPU path", streamPtr->compressionLevel); return 0; }
+    r = lzgpu_compress_one(src, srcSize, dst, maxDstSize, streamPtr->compressionLevel);
+    if (r < 0) { complain("GPU compression failed", streamPtr->compressionLevel); return 0; }
+    if (srcSize > 0) {                                           /* :560-561: contiguous input extends the prefix, anything else starts a new one */
+        streamPtr->prefix = (src == streamPtr->end ? streamPtr->prefix : 0) + (size_t)srcSize;
+        streamPtr->end = src + srcSize;
+    }
+    return r;
+}

@@ -65,26 +65,21 @@ struct LzStreams {
 #else
 #define LZ_PROF(st, k) ((void)0)
 #endif
-#define LZ_SCRATCH_BYTES (4u * LZ_SUBBLOCK_PAD)
-// Scratch slot of one wave (global memory).  priceFast: four stream staging areas of LZ_SUBBLOCK_PAD bytes.
-// Fast parser: [0, 256 KiB) sequence list (8 B per sequence, at most 131072/4 sequences per sub-block),
-// then a literals staging area and a flags staging area that only the Huffman levels use (levels without
-// Huffman write both streams straight into dst).
+#define LZ_SCRATCH_BYTES (5u * LZ_SUBBLOCK_PAD)
+// Scratch slot of one wave (global memory): the sequence list of the current sub-block (8 B per sequence), then a
+// literals staging area and a flags staging area that only the Huffman levels use (levels without Huffman write
+// every stream straight into dst).  fastLZ4 codewords: matches are >= 4 bytes, at most 131072/4 sequences (256 KiB);
+// LIZv1: a trimmed second match may be 3 bytes long (pricefast.h:225), at most 131072/3 sequences (352 KiB).
 #define LZ_SEQ_BYTES     (1u << 18)
+#define LZ_SEQ_BYTES_LIZ (352u << 10)
 #define LZ_SEQ_RING      32u                            // sequences buffered in LDS (256 B per wave)
 
-LZ_DEV void lz_streams_bind(LzStreams& st, u8* scratch, bool fastParser, u64* ring)
+LZ_DEV void lz_streams_bind(LzStreams& st, u8* scratch, bool lz4Codewords, u64* ring)
 {
     st.ring = ring;
-    if (fastParser) {
-        st.seq = (u64*)scratch;
-        st.lit = scratch + LZ_SEQ_BYTES; st.flags = st.lit + LZ_SUBBLOCK_PAD;      // 256 KiB + 128 KiB+32 + 32 KiB < slot
-        st.off16 = st.off24 = st.flags;                                            // never written by fastLZ4 codewords
-    } else {
-        st.seq = (u64*)scratch;
-        st.lit = scratch; st.flags = scratch + LZ_SUBBLOCK_PAD;
-        st.off16 = scratch + 2 * LZ_SUBBLOCK_PAD; st.off24 = scratch + 3 * LZ_SUBBLOCK_PAD;
-    }
+    st.seq = (u64*)scratch;
+    st.lit = scratch + (lz4Codewords ? LZ_SEQ_BYTES : LZ_SEQ_BYTES_LIZ); st.flags = st.lit + LZ_SUBBLOCK_PAD;
+    st.off16 = st.off24 = st.flags;                                                // offset streams are never staged
     st.nlit = st.nflags = st.noff16 = st.noff24 = 0;
     st.nseq = 0; st.lastLits = 0;
 }
@@ -171,8 +166,8 @@ LZ_DEV void lz_copy(u8* dst, const u8* src, u32 n)
 {
     const u32 lane = lz_lane();
     const u32 n4 = n & ~3u;
-    for (u32 i = lane * 4u; i < n4; i += 256u) lz_st32(dst + i, lz_ld32(src + i));
-    for (u32 i = n4 + lane; i < n; i += 64u) dst[i] = src[i];
+    for (u32 i = lane * 4u; i < n4; i += 256u) lz_st32_s(dst + i, lz_ld32_s(src + i));
+    for (u32 i = n4 + lane; i < n; i += 64u) lz_st8_s(dst + i, lz_ld8_s(src + i));
 }
 
 // Length escape shared by all codewords (reference lib/lizard_compress_lz4.h:21-23), as a packed
@@ -199,7 +194,7 @@ LZ_DEV void lz_seq_flush(LzStreams& st)
 {
     const u32 pending = st.nseq & (LZ_SEQ_RING - 1u) ? st.nseq & (LZ_SEQ_RING - 1u) : (st.nseq ? LZ_SEQ_RING : 0u);
     lz_lds_sync();
-    if (lz_lane() < pending) st.seq[st.nseq - pending + lz_lane()] = st.ring[lz_lane()];
+    if (lz_lane() < pending) lz_stq_s(&st.seq[st.nseq - pending + lz_lane()], st.ring[lz_lane()]);
     lz_lds_sync();
 }
 LZ_DEV void lz_seq_push(LzStreams& st, u32 L, u32 ml, u32 off)
@@ -210,6 +205,48 @@ LZ_DEV void lz_seq_push(LzStreams& st, u32 L, u32 ml, u32 off)
     st.nseq += 1u; st.nflags += 1u;
     st.nlit += lz_lz4_record_bytes(L, mlc);
     if ((st.nseq & (LZ_SEQ_RING - 1u)) == 0) lz_seq_flush(st);
+}
+
+// Literal runs of one encode step (64 sequences, one per lane): run of lane j = L bytes from src + mySrc to
+// litOut + litAt.  Vector-memory cost on this path is per instruction, not per byte, so one load/store pair serves
+// EIGHT runs: lane l works on run 8g + (l >> 3) with sub-lane s = l & 7.  Runs of >= 8 bytes move 8 bytes per
+// sub-lane (the last piece is pulled back to end exactly at the run's end; overlapping pieces rewrite identical
+// bytes), shorter runs one byte per sub-lane.  All loads of the step are issued before the first store (loads and
+// stores return through one in-order counter on gfx950).  Lanes without a sequence pass L = 0.
+LZ_DEV void lz_copy_literal_runs(const u8* src, u8* litOut, u32 mySrc, u32 litAt, u32 L)
+{
+    const u32 lane = lz_lane();
+    {
+        u64 w8[8]; u32 w1[8];
+        #pragma unroll
+        for (u32 g = 0; g < 8u; g++) {
+            const u32 jr = 8u * g + (lane >> 3), sl = lane & 7u;
+            const u32 a = lz_shfl(mySrc, jr), nj = lz_shfl(L, jr);
+            const u32 n64 = nj < 64u ? nj : 64u;              // bytes beyond 64 are copied below
+            const u32 k = 8u * sl + 8u <= n64 ? 8u * sl : n64 - 8u;
+            w8[g] = (n64 >= 8u && 8u * sl < n64) ? lz_ld64_s(src + a + k) : 0ull;
+            w1[g] = (n64 < 8u && sl < n64) ? lz_ld8_s(src + a + sl) : 0u;
+        }
+        #pragma unroll
+        for (u32 g = 0; g < 8u; g++) {
+            const u32 jr = 8u * g + (lane >> 3), sl = lane & 7u;
+            const u32 o = lz_shfl(litAt, jr), nj = lz_shfl(L, jr);
+            const u32 n64 = nj < 64u ? nj : 64u;
+            const u32 k = 8u * sl + 8u <= n64 ? 8u * sl : n64 - 8u;
+            if (n64 >= 8u && 8u * sl < n64) lz_st64_s(litOut + o + k, w8[g]);
+            if (n64 < 8u && sl < n64) lz_st8_s(litOut + o + sl, w1[g]);
+        }
+    }
+    // runs longer than 64 bytes (on the benchmark data the mean run is 76 bytes, so these are common): the
+    // rest of one run per iteration, 8 bytes per lane, the last piece pulled back to end at the run's end
+    for (u64 longRuns = lz_ballot(L > 64u); longRuns; longRuns &= longRuns - 1ull) {
+        const u32 j = lz_ctz64(longRuns);
+        const u32 nj = lz_readlane(L, j), a = lz_readlane(mySrc, j), o = lz_readlane(litAt, j);
+        for (u32 k = 64u + 8u * lane; k < nj; k += 512u) {
+            const u32 kk = k + 8u <= nj ? k : nj - 8u;
+            lz_st64_s(litOut + o + kk, lz_ld64_s(src + a + kk));
+        }
+    }
 }
 
 // Wave-parallel fastLZ4 encoder (reference lib/lizard_compress_lz4.h:3-86) over the sequence list of the
@@ -226,7 +263,7 @@ LZ_DEV void lz_encode_lz4(const u8* src, u32 S, const LzStreams& st, u8* litOut,
         const u32 cnt = st.nseq - base < 64u ? st.nseq - base : 64u;
         u32 L = 0, mlc = 0, off = 0, R = 0, adv = 0;
         if (lane < cnt) {
-            const u64 q = st.seq[base + lane];
+            const u64 q = lz_ldq_s(&st.seq[base + lane]);
             L = (u32)q & 0x3FFFFu; mlc = (u32)(q >> 18) & 0x3FFFFu; off = (u32)(q >> 36);
             R = lz_lz4_record_bytes(L, mlc); adv = L + mlc + 4u;
         }
@@ -236,62 +273,18 @@ LZ_DEV void lz_encode_lz4(const u8* src, u32 S, const LzStreams& st, u8* litOut,
         lz_len_ext(L >= 15u, L - 15u, extLw, extLn);
         lz_len_ext(mlc >= 15u, mlc - 15u, extMw, extMn);
         if (lane < cnt) {
-            flagsOut[base + lane] = (u8)((L >= 15u ? 15u : L) | ((mlc >= 15u ? 15u : mlc) << 4));
+            lz_st8_s(flagsOut + base + lane, (L >= 15u ? 15u : L) | ((mlc >= 15u ? 15u : mlc) << 4));
             u8* r = litOut + myOut;
-            for (u32 k = 0; k < extLn; k++) r[k] = (u8)(extLw >> (8u * k));
+            for (u32 k = 0; k < extLn; k++) lz_st8_s(r + k, extLw >> (8u * k));
             r += extLn + L;
-            lz_st16(r, off);
-            for (u32 k = 0; k < extMn; k++) r[2u + k] = (u8)(extMw >> (8u * k));
+            lz_st16_s(r, off);
+            for (u32 k = 0; k < extMn; k++) lz_st8_s(r + 2u + k, extMw >> (8u * k));
         }
-        // literal runs.  Vector-memory cost on this path is per instruction, not per byte, so one
-        // load/store pair serves EIGHT runs: lane l works on run 8g + (l >> 3) with sub-lane s = l & 7.
-        // Runs of >= 8 bytes move 8 bytes per sub-lane (the last piece is pulled back to end exactly at
-        // the run's end; overlapping pieces rewrite identical bytes), shorter runs one byte per sub-lane.
-        // All loads of the step are issued before the first store (loads and stores return through one
-        // in-order counter on gfx950).
-        const u32 litAt = myOut + extLn;
-        {
-            u64 w8[8]; u32 w1[8];
-            #pragma unroll
-            for (u32 g = 0; g < 8u; g++) {
-                const u32 jr = 8u * g + (lane >> 3), sl = lane & 7u;
-                const u32 a = lz_shfl(mySrc, jr), nj = lz_shfl(L, jr);
-                const u32 n64 = nj < 64u ? nj : 64u;              // bytes beyond 64 are copied below
-                const u32 k = 8u * sl + 8u <= n64 ? 8u * sl : n64 - 8u;
-                w8[g] = (n64 >= 8u && 8u * sl < n64) ? lz_ld64(src + a + k) : 0ull;
-                w1[g] = (n64 < 8u && sl < n64) ? src[a + sl] : 0u;
-            }
-            #pragma unroll
-            for (u32 g = 0; g < 8u; g++) {
-                const u32 jr = 8u * g + (lane >> 3), sl = lane & 7u;
-                const u32 o = lz_shfl(litAt, jr), nj = lz_shfl(L, jr);
-                const u32 n64 = nj < 64u ? nj : 64u;
-                const u32 k = 8u * sl + 8u <= n64 ? 8u * sl : n64 - 8u;
-                if (n64 >= 8u && 8u * sl < n64) lz_st64(litOut + o + k, w8[g]);
-                if (n64 < 8u && sl < n64) litOut[o + sl] = (u8)w1[g];
-            }
-        }
-        // runs longer than 64 bytes (on the benchmark data the mean run is 76 bytes, so these are common): the
-        // rest of one run per iteration, 8 bytes per lane, the last piece pulled back to end at the run's end
-        for (u64 longRuns = lz_ballot(L > 64u); longRuns; longRuns &= longRuns - 1ull) {
-            const u32 j = lz_ctz64(longRuns);
-            const u32 nj = lz_readlane(L, j), a = lz_readlane(mySrc, j), o = lz_readlane(litAt, j);
-            for (u32 k = 64u + 8u * lane; k < nj; k += 512u) {
-                const u32 kk = k + 8u <= nj ? k : nj - 8u;
-                lz_st64(litOut + o + kk, lz_ld64(src + a + kk));
-            }
-        }
+        lz_copy_literal_runs(src, litOut, mySrc, myOut + extLn, L);
         srcPos = lz_readlane(mySrc + adv, 63u);                   // lanes >= cnt hold adv == R == 0
         outPos = lz_readlane(myOut + R, 63u);
     }
     lz_copy(litOut + outPos, src + srcPos, st.lastLits);          // lizard_compress_lz4.h:74-86
-}
-
-// Trailing literals of a sub-block (reference lib/lizard_compress_lz4.h:74-86): raw, no token.
-LZ_DEV void lz_emit_last_literals(const u8* src, u32 anchor, u32 E, LzStreams& st)
-{
-    lz_copy(st.lit + st.nlit, src + anchor, E - anchor);
-    st.nlit += E - anchor;
 }
 
 // ---- fastSmall / fast parser over one sub-block [S,E) of the block at `src` ----------------------
@@ -323,13 +316,6 @@ struct LzTab {
 // One extra slot (index 2^HASHLOG, "trash") lets lanes that must not store do so anyway, branch-free.
 #define LZ_TAB_BYTES(HASHLOG) ((3u << (HASHLOG)) + 4u)
 template <int HASHLOG> LZ_DEV LzTab lz_tab_bind(void* mem) { LzTab t; t.lo = (u16*)mem; t.hi = (u8*)mem + (2u << HASHLOG) + 2u; return t; }
-LZ_DEV u32 lz_tab_get(const LzTab& t, u32 h) { return t.get(h); }
-LZ_DEV void lz_tab_set(const LzTab& t, u32 h, u32 ent) { t.set(h, ent); }
-// The same 24-bit values in u32 slots, for tables kept in global memory: every access there is a random
-// memory sector, and the split u16 + u8 layout would cost two of them per get and per set.
-struct LzTab32 { u32* w; };
-LZ_DEV u32 lz_tab_get(const LzTab32& t, u32 h) { return t.w[h]; }
-LZ_DEV void lz_tab_set(const LzTab32& t, u32 h, u32 ent) { t.w[h] = ent; }
 // Re-stamp every slot that is dead at position Ps (age >= 65536); with `fresh`: all empty.
 template <int HASHLOG>
 LZ_DEV void lz_tab_sweep(const LzTab& t, u32 Ps, bool fresh)
@@ -489,11 +475,15 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
             // round and the vmcnt arithmetic of the batch above stays exact.
             nextBytes = lz_ld64(src + pAhead);
             LZ_PROF(st, 0);                                              // round part A: bytes wait, hash, LDS, filter, loads issued
-            const bool ok = cand && (u32)cA == first4;                   // fast.h:97
             // match lengths from the batch, already clamped like the reference's counts (fast.h:100,102):
             // exact when the difference (or the limit) lies inside the fetched bytes, else 0xFFFF = unresolved
+            bool ok = false;
             u32 fwd = 0xFFFFu, bwd = 0xFFFFu;
+#ifdef LZ_SKIP_NOCAND
+            if (lz_ballot(cand))                                         // most rounds have no candidate at all: no batch, nothing to measure
+#endif
             {
+                ok = cand && (u32)cA == first4;                          // fast.h:97
                 const u64 x = bytes ^ cA, y = pB ^ cB, y2 = pC ^ cC, z = pZ ^ cZ;
                 const u32 seen = have24 ? 24u : 16u;
                 const u32 common = x ? lz_ctz64(x) >> 3 : y ? 8u + (lz_ctz64(y) >> 3) : (have24 && y2) ? 16u + (lz_ctz64(y2) >> 3) : seen;
@@ -558,104 +548,39 @@ LZ_DEV void lz_st24(u8* p, u32 v) { p[0] = (u8)v; p[1] = (u8)(v >> 8); p[2] = (u
 
 // ---- sub-block container (reference lib/lizard_compress.c:141-250) -------------------------------
 
-// Raw stream: LE24 length + bytes (lizard_compress.c:176-182). Returns bytes written. All lanes call.
-LZ_DEV u32 lz_put_stream_raw(u8* op, const u8* stream, u32 n)
+// Lizard_writeBlock (reference lib/lizard_compress.c:186-250) over the sequence list of one sub-block.  The stream
+// sizes are known from the parse, so the raw-fallback rule of :201 is decided before a single output byte exists;
+// without Huffman also :228, and every stream is encoded straight into its final place in dst (order: len (always
+// empty), off16, off24, flags, literals; each LE24 length + bytes).  With Huffman the two candidate streams
+// (huffType = LITERALS + FLAGS, lizard_compress.c:374-377) are encoded into the staging areas first (the entropy
+// stage needs them contiguous); the offset streams still go straight to dst.  LIZ: LIZv1 codewords (priceFast),
+// else fastLZ4 codewords (whose off16/off24 streams are always empty).
+template <bool HUF, bool LIZ>
+LZ_DEV u32 lz_write_subblock_seq(const u8* src, u32 S, u32 E, u8* op, LzStreams& st, u32* ws)
 {
-    if (lz_lane() == 0) lz_st24(op, n);
-    lz_converge();
-    lz_copy(op + 3, stream, n);
-    return 3u + n;
-}
-
-// Lizard_writeBlock without the Huffman stage (levels < 30). `in` = first byte of the sub-block.
-// Returns the bytes written at `op` (uniform). The caller guarantees room for n + 4 bytes.
-LZ_DEV u32 lz_write_subblock_raw_streams(const u8* in, u32 n, u8* op, LzStreams& st)
-{
-    const u32 sum = st.nflags + st.nlit + st.noff16 + st.noff24;
-    const u32 total = 16u + sum;                              // header + 5 x LE24 + streams
-    // lizard_compress.c:201 and :228
-    const bool raw = st.nlit < LZ_LASTLITERALS || sum + 16u > n || total + total / 32u + 512u > n;
-    if (raw) {
-        if (lz_lane() == 0) { op[0] = 128; lz_st24(op + 1, n); }   // LIZARD_FLAG_UNCOMPRESSED, :239-244
-        lz_converge();
-        lz_copy(op + 4, in, n);
-        return n + 4u;
-    }
-    lz_wave_sync();                                           // stream bytes written by other lanes
-    u8* q = op;
-    if (lz_lane() == 0) { q[0] = 0; lz_st24(q + 1, 0); }      // header byte, empty `len` stream (:203-207)
-    lz_converge();
-    q += 4;
-    q += lz_put_stream_raw(q, st.off16, st.noff16);           // :209
-    q += lz_put_stream_raw(q, st.off24, st.noff24);           // :212
-    q += lz_put_stream_raw(q, st.flags, st.nflags);           // :215
-    q += lz_put_stream_raw(q, st.lit, st.nlit);               // :221
-    return total;
-}
-
-// Lizard_writeBlock with the Huffman stage (levels >= 30): huffType = LITERALS + FLAGS
-// (lizard_compress.c:374-377); off16/off24/len streams are always stored raw.  ws = LDS workspace of
-// LZ_HUF_WS_WORDS words (aliases the parser's tag array, which is idle here).
-LZ_DEV u32 lz_write_subblock_huf(const u8* in, u32 n, u8* op, LzStreams& st, u32* ws)
-{
-    const u32 sum = st.nflags + st.nlit + st.noff16 + st.noff24;
-    bool raw = st.nlit < LZ_LASTLITERALS || sum + 16u > n;             // lizard_compress.c:201
-    u32 total = 0;
-    if (!raw) {
-        lz_wave_sync();
-        u32 hf = 0, hl = 0;
-        u8* q = op + 1;
-        if (lz_lane() == 0) lz_st24(q, 0);                             // empty `len` stream
-        lz_converge();
-        q += 3;
-        q += lz_put_stream_raw(q, st.off16, st.noff16);
-        q += lz_put_stream_raw(q, st.off24, st.noff24);
-        q += lz_put_stream_huf(q, st.flags, st.nflags, ws, &hf LZ_HPROF_ARG(st));       // LIZARD_FLAG_FLAGS = 2
-        q += lz_put_stream_huf(q, st.lit, st.nlit, ws, &hl LZ_HPROF_ARG(st));           // LIZARD_FLAG_LITERALS = 1
-        total = (u32)(q - op);
-        if (lz_lane() == 0) op[0] = (u8)(hl * 1u + hf * 2u);
-        lz_converge();
-        raw = total + total / 32u + 512u > n;                          // lizard_compress.c:228
-    }
-    if (raw) {
-        lz_wave_sync();
-        if (lz_lane() == 0) { op[0] = 128; lz_st24(op + 1, n); }
-        lz_converge();
-        lz_copy(op + 4, in, n);
-        return n + 4u;
-    }
-    return total;
-}
-
-// Lizard_writeBlock for the fast parser (reference lib/lizard_compress.c:186-250): the stream sizes are
-// known from the parse (nseq tokens, nlit literal-stream bytes), so the raw-fallback rules of :201 are
-// decided before a single output byte exists; without Huffman also :228, and both streams are encoded
-// straight into their final place in dst.  With Huffman they are encoded into the staging areas first
-// (the entropy stage needs them contiguous), then written like lz_write_subblock_huf.
-template <bool HUF>
-LZ_DEV u32 lz_write_subblock_fast(const u8* src, u32 S, u32 E, u8* op, LzStreams& st, u32* ws)
-{
-    const u32 n = E - S, sum = st.nflags + st.nlit;
+    const u32 n = E - S, sum = st.nflags + st.nlit + st.noff16 + st.noff24;
     bool raw = st.nlit < LZ_LASTLITERALS || sum + 16u > n;             // lizard_compress.c:201
     u32 total = 16u + sum;
     if (!HUF) raw = raw || total + total / 32u + 512u > n;             // :228 (sizes are final without Huffman)
     if (!raw) {
         lz_wave_sync();                                                // sequence list written by lane 0
+        u8* const p16 = op + 4u;                                       // header byte, LE24 0 = empty `len` stream (:203-207)
+        u8* const p24 = p16 + 3u + st.noff16;                          // :209
+        u8* const pf = p24 + 3u + st.noff24;                           // :212
+        if (lz_lane() == 0) { op[0] = 0; lz_st24(op + 1, 0); lz_st24(p16, st.noff16); lz_st24(p24, st.noff24); }
+        lz_converge();
         if constexpr (!HUF) {
-            if (lz_lane() == 0) {
-                op[0] = 0; lz_st24(op + 1, 0); lz_st24(op + 4, 0); lz_st24(op + 7, 0);   // header, empty len/off16/off24 (:203-213)
-                lz_st24(op + 10, st.nflags); lz_st24(op + 13 + st.nflags, st.nlit);      // :215, :221
-            }
+            u8* const pl = pf + 3u + st.nflags;
+            if (lz_lane() == 0) { lz_st24(pf, st.nflags); lz_st24(pl, st.nlit); }        // :215, :221
             lz_converge();
-            lz_encode_lz4(src, S, st, op + 16u + st.nflags, op + 13u);
+            if constexpr (LIZ) lz_encode_lizv1(src, S, st, pl + 3u, pf + 3u, p16 + 3u, p24 + 3u);
+            else               lz_encode_lz4(src, S, st, pl + 3u, pf + 3u);
         } else {
-            lz_encode_lz4(src, S, st, st.lit, st.flags);
+            if constexpr (LIZ) lz_encode_lizv1(src, S, st, st.lit, st.flags, p16 + 3u, p24 + 3u);
+            else               lz_encode_lz4(src, S, st, st.lit, st.flags);
             lz_wave_sync();
             u32 hf = 0, hl = 0;
-            u8* q = op + 1;
-            if (lz_lane() == 0) { lz_st24(q, 0); lz_st24(q + 3, 0); lz_st24(q + 6, 0); }
-            lz_converge();
-            q += 9;
+            u8* q = pf;
             q += lz_put_stream_huf(q, st.flags, st.nflags, ws, &hf LZ_HPROF_ARG(st));   // LIZARD_FLAG_FLAGS = 2
             q += lz_put_stream_huf(q, st.lit, st.nlit, ws, &hl LZ_HPROF_ARG(st));       // LIZARD_FLAG_LITERALS = 1
             total = (u32)(q - op);
@@ -676,33 +601,42 @@ LZ_DEV u32 lz_write_subblock_fast(const u8* src, u32 S, u32 E, u8* op, LzStreams
 
 // ---- one API block: reference Lizard_compress_extState on a zeroed state (lizard_compress.c:583) ----
 // dst must have room for Lizard_compressBound(n) bytes. Returns the compressed size (uniform).
-// seqRing:  fast parser -> LZ_SEQ_RING u64 of LDS (may be null for priceFast).
-// tableMem: LZ_TAB_BYTES(HASHLOG) bytes (24-bit slots, see LzTab) — priceFast with tab32: 4 << HASHLOG bytes of
-//           u32 slots (LzTab32, for tables in global memory); fast parser with HASHLOG > 14:
-//           LZ_TABWIDE_BYTES(HASHLOG) bytes of 16-byte aligned global memory (LzTabWide, blocks <= 4 MiB).
-// AUX:      priceFast only -> TAGLOG of the round tag array.
+// seqRing:  LZ_SEQ_RING u64 of LDS.
+// tabKind / tableMem — where and how this wave keeps its hash table:
+//   LZ_TABKIND_LDS     fast parser: LZ_TAB_BYTES(HASHLOG) bytes of LDS (24-bit slots with check bits, LzTab);
+//                      priceFast: the same size, 24-bit positions (LzTabPf24, blocks < 16 MiB)
+//   LZ_TABKIND_GLOBAL  u32 slots in global memory: fast parser LZ_TABWIDE_BYTES(HASHLOG) bytes, 16-byte aligned
+//                      (LzTabWide, blocks <= 4 MiB; the only form for HASHLOG > 14); priceFast 4 << HASHLOG bytes (LzTab32)
+//   LZ_TABKIND_LDS18   priceFast only: LZ_TAB18_BYTES(HASHLOG) bytes of LDS, 18-bit positions (LzTab18, blocks <= 256 KiB)
+// AUX:      priceFast -> TAGLOG of the round tag array (ws holds 2^TAGLOG bytes of LDS).
 //           hashChain -> searchLength (4 or 5); tableMem = the wave's LZ_HC_SLOT_BYTES slot (global, zeroed once by
 //           the host), ws doubles as the 2^LZ_HC_TAGLOG-byte tag array.
 // PARSER: 0 = fastSmall/fast + fastLZ4 codewords, 1 = priceFast + LIZv1 codewords, 2 = hashChain + fastLZ4 codewords.
 #define LZ_PARSER_FAST      0
 #define LZ_PARSER_PRICEFAST 1
 #define LZ_PARSER_HASHCHAIN 2
+#define LZ_TABKIND_LDS      0u
+#define LZ_TABKIND_GLOBAL   1u
+#define LZ_TABKIND_LDS18    2u
 template <int PARSER, int HASHLOG, int AUX, bool HUF>
 LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tableMem, u8* ws, u8* scratch, u64* seqRing,
-                             bool tab32 = false)
+                             u32 tabKind = LZ_TABKIND_LDS)
 {
     const u32 lane = lz_lane();
     LzStreams st;
-    constexpr bool kSeqList = PARSER == LZ_PARSER_FAST || PARSER == LZ_PARSER_HASHCHAIN;   // fastLZ4 codewords
-    lz_streams_bind(st, scratch, kSeqList, seqRing);
+    constexpr bool kLiz = PARSER == LZ_PARSER_PRICEFAST;                                   // LIZv1 codewords
+    lz_streams_bind(st, scratch, !kLiz, seqRing);
 #ifdef LZ_PROFILE
     st.prof_last = __builtin_readcyclecounter();
     for (int k = 0; k < 16; k++) st.prof[k] = 0;
 #endif
-    // fast parser: 24-bit LDS slots up to hashLog 14, wide u32 slots in global memory above; priceFast: 24-bit LDS slots
+    // fast parser: 24-bit LDS slots up to hashLog 14, wide u32 slots in global memory above
     constexpr bool kWide = PARSER == LZ_PARSER_FAST && HASHLOG > 14;
     LzTab tab = lz_tab_bind<kWide ? 1 : HASHLOG>(tableMem);
     LzTabWide tabw; tabw.w = (u32*)tableMem; tabw.tag = ws;
+    LzTabPf24 pf24; pf24.lo = tab.lo; pf24.hi = tab.hi;
+    LzTab32 pf32; pf32.w = (u32*)tableMem;
+    LzTab18 pf18; pf18.lo = (u16*)tableMem; pf18.hi = (u32*)((u8*)tableMem + (2u << (kWide ? 1 : HASHLOG)));
     LzHc hc;
     if constexpr (PARSER == LZ_PARSER_HASHCHAIN) {
         const u32 row = (level >= 30u ? level - 21u : level) - 13u;                  // lizard_common.h:240-244, :264-268
@@ -710,10 +644,13 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
         lz_hc_build<AUX>(src, n, hc);
     }
     else if constexpr (kWide) lz_tab_fresh<HASHLOG>(tabw);
-    else if (PARSER == LZ_PARSER_FAST && tab32) lz_tab_fresh<HASHLOG>(tabw);
-    else if constexpr (PARSER == LZ_PARSER_FAST) { lz_tab_fresh<HASHLOG>(tab); st.sweepAt = 32768u; }
-    else if (tab32) { LzTab32 t32; t32.w = (u32*)tableMem; for (u32 i = lane; i < (1u << HASHLOG); i += 64u) lz_tab_set(t32, i, LZ_EMPTY24); }
-    else for (u32 i = lane; i < (1u << HASHLOG); i += 64u) lz_tab_set(tab, i, LZ_EMPTY24);
+    else if constexpr (PARSER == LZ_PARSER_FAST) {
+        if (tabKind == LZ_TABKIND_GLOBAL) lz_tab_fresh<HASHLOG>(tabw);
+        else { lz_tab_fresh<HASHLOG>(tab); st.sweepAt = 32768u; }
+    }
+    else if (tabKind == LZ_TABKIND_GLOBAL) lz_pf_tab_fresh<HASHLOG>(pf32);
+    else if (tabKind == LZ_TABKIND_LDS18)  lz_pf_tab_fresh<HASHLOG>(pf18);
+    else                                   lz_pf_tab_fresh<HASHLOG>(pf24);
     lz_wave_sync();
     LZ_PROF(st, 6);                                           // table init
     if (lane == 0) dst[0] = (u8)level;                        // lizard_compress.c:488
@@ -725,14 +662,15 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
         st.nseq = 0; st.lastLits = 0;
         if constexpr (PARSER == LZ_PARSER_HASHCHAIN) lz_parse_hashchain(src, pos, pos + part, hc, st);
         else if constexpr (kWide)                    lz_parse_fast<HASHLOG>(src, pos, pos + part, tabw, st);
-        else if (PARSER == LZ_PARSER_FAST && tab32)  lz_parse_fast<HASHLOG>(src, pos, pos + part, tabw, st);
-        else if constexpr (PARSER == LZ_PARSER_FAST) lz_parse_fast<HASHLOG>(src, pos, pos + part, tab, st);
-        else if (tab32) { LzTab32 t32; t32.w = (u32*)tableMem; lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, t32, ws, st); }
-        else                                    lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, tab, ws, st);
-        if constexpr (kSeqList)                 op += lz_write_subblock_fast<HUF>(src, pos, pos + part, dst + op, st, (u32*)ws);
-        else if constexpr (HUF)                 op += lz_write_subblock_huf(src + pos, part, dst + op, st, (u32*)ws);
-        else                                    op += lz_write_subblock_raw_streams(src + pos, part, dst + op, st);
-        LZ_PROF(st, 5);                                       // container: encode pass / stream copies / Huffman
+        else if constexpr (PARSER == LZ_PARSER_FAST) {
+            if (tabKind == LZ_TABKIND_GLOBAL) lz_parse_fast<HASHLOG>(src, pos, pos + part, tabw, st);
+            else                              lz_parse_fast<HASHLOG>(src, pos, pos + part, tab, st);
+        }
+        else if (tabKind == LZ_TABKIND_GLOBAL) lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, pf32, ws, st);
+        else if (tabKind == LZ_TABKIND_LDS18)  lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, pf18, ws, st);
+        else                                   lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, pf24, ws, st);
+        op += lz_write_subblock_seq<HUF, kLiz>(src, pos, pos + part, dst + op, st, (u32*)ws);
+        LZ_PROF(st, 5);                                       // container: encode pass / Huffman
         lz_wave_sync();                                       // scratch is reused by the next sub-block
         LZ_PROF(st, 4);                                       // draining the sub-block's stores
         pos += part;

@@ -11,8 +11,19 @@
 // obtained by walking that group's members in lane order with scalar code; every lane also records
 // the slot value AFTER its own update, and the last same-slot lane up to the winner stores it.
 // Everything after the winner (back-extension, the one-step lazy re-search at ip+ml-2 and its overlap
-// arbitration, encoding) is a serial chain per sequence and runs as wave-uniform scalar code around
-// the wave-parallel byte-compare / copy helpers.
+// arbitration) is a serial chain per sequence and runs as wave-uniform scalar code around the
+// wave-parallel byte-compare helpers.
+//
+// Encoding is not on the serial path (same structure as the fast parser, lz_block.h): the parse appends
+// (literal run, match length, offset | 0 = repeat) to a sequence list through an LDS ring and keeps the four
+// stream sizes up to date, so the container's raw-fallback rules (lizard_compress.c:201,228) are decided
+// before any output exists; lz_encode_lizv1 then writes tokens, literals and both offset streams 64
+// sequences per step straight into their final place in dst (staging only in front of the Huffman stage).
+//
+// Memory latency structure of a round: the 8 source bytes of every lane and its repeat-offset candidate are
+// requested together (both addresses are known before the table is read); the hash candidate follows the
+// LDS (or global) table read.  All loads are unconditional with clamped addresses, so no exec-masked load
+// forces an early vmcnt(0).
 //
 // Included from lz_block.h after the shared helpers.
 #pragma once
@@ -20,58 +31,125 @@
 #define LZ_16BIT_OFFSET 65536u      // LIZARD_MAX_16BIT_OFFSET, lizard_common.h:83
 #define LZ_MM_LONGOFF   16u         // MM_LONGOFF, lizard_common.h:84 (minMatchLongOff of levels 20-29/40-49)
 
-// LIZv1 sequence (reference lib/lizard_compress_liz.h:43-165). M == P encodes "repeat last offset".
-// Updates last_off like the reference (liz.h:119,135). All lanes call; values uniform.
-LZ_DEV void lz_emit_lizv1(const u8* src, u32 anchor, u32 P, u32 ml, u32 M, LzStreams& st, u32& last_off)
+// ---- hash tables of the priceFast levels (ours; only the parse RESULT is pinned by the reference) ----
+// All hold block-relative positions; kEmpty is a value no probe position reaches, so an empty slot fails
+// "e < p" like the reference's zeroed slot fails "e >= lowLimit" and is always overwritten (:170-171).
+//   LzTab   (lz_block.h)  u16 + u8 arrays, 24-bit positions: blocks < 16 MiB, 48 KiB of LDS at hashLog 14
+//   LzTab18               u16 array + 2 bits per slot packed 16 to a dword (ds_mskor): 18-bit positions, i.e.
+//                         blocks <= 256 KiB — the benchmark configuration — in 36 KiB: four tables per CU instead
+//                         of three (the waves whose table is in LDS are ~5x faster than the others)
+//   LzTab32               u32 slots in global memory (one sector per access)
+#define LZ_EMPTY24 0xFFFFFFu
+#define LZ_EMPTY18 0x3FFFFu
+struct LzTabPf24 {
+    u16* lo; u8* hi;
+    static constexpr u32 kEmpty = LZ_EMPTY24;
+    LZ_DEVM u32  get(u32 h) const { return (u32)lo[h] | ((u32)hi[h] << 16); }
+    LZ_DEVM void set(u32 h, u32 v) const { lo[h] = (u16)v; hi[h] = (u8)(v >> 16); }
+    LZ_DEVM void sync() const { lz_lds_sync(); }
+};
+struct LzTab18 {
+    u16* lo; u32* hi;
+    static constexpr u32 kEmpty = LZ_EMPTY18;
+    LZ_DEVM u32  get(u32 h) const { return (u32)lo[h] | (((hi[h >> 4] >> (2u * (h & 15u))) & 3u) << 16); }
+    LZ_DEVM void set(u32 h, u32 v) const { lo[h] = (u16)v; lz_lds_mskor(&hi[h >> 4], 3u << (2u * (h & 15u)), (v >> 16) << (2u * (h & 15u))); }
+    LZ_DEVM void sync() const { lz_lds_sync(); }
+};
+#define LZ_TAB18_BYTES(HASHLOG) ((2u << (HASHLOG)) + ((1u << (HASHLOG)) >> 2))
+struct LzTab32 {
+    u32* w;
+    static constexpr u32 kEmpty = LZ_EMPTY24;
+    LZ_DEVM u32  get(u32 h) const { return w[h]; }
+    LZ_DEVM void set(u32 h, u32 v) const { w[h] = v; }
+    LZ_DEVM void sync() const { lz_wave_sync(); }
+};
+template <int HASHLOG> LZ_DEV void lz_pf_tab_fresh(const LzTabPf24& t) { for (u32 i = lz_lane(); i < (1u << HASHLOG); i += 64u) t.set(i, LZ_EMPTY24); }
+template <int HASHLOG> LZ_DEV void lz_pf_tab_fresh(const LzTab32& t) { for (u32 i = lz_lane(); i < (1u << HASHLOG); i += 64u) t.w[i] = LZ_EMPTY24; }
+template <int HASHLOG> LZ_DEV void lz_pf_tab_fresh(const LzTab18& t)
+{
+    for (u32 i = lz_lane(); i < (1u << HASHLOG) / 2u; i += 64u) ((u32*)t.lo)[i] = 0xFFFFFFFFu;
+    for (u32 i = lz_lane(); i < (1u << HASHLOG) / 16u; i += 64u) t.hi[i] = 0xFFFFFFFFu;
+}
+
+// ---- sequence list (LIZv1): L < 2^18, ml < 2^18, off < 2^24 (0 = repeat the last offset) ----
+// Stream sizes exactly as the encoder will produce them (reference lib/lizard_compress_liz.h:43-165).
+LZ_DEV void lz_seq_push_liz(LzStreams& st, u32 L, u32 ml, u32 off)
+{
+    const bool longOff = off >= LZ_16BIT_OFFSET;
+    if (lz_lane() == 0) st.ring[st.nseq & (LZ_SEQ_RING - 1u)] = (u64)L | ((u64)ml << 18) | ((u64)off << 36);
+    lz_converge();
+    const u32 m = longOff ? ml - LZ_MM_LONGOFF : ml;
+    const u32 mSat = longOff ? 31u : 15u;
+    st.nseq += 1u;
+    st.nlit += lz_ext_len(L >= 7u, L - 7u) + L + lz_ext_len(m >= mSat, m - mSat);
+    st.nflags += (longOff && L > 0u) ? 2u : 1u;                              // liz.h:83-93: literal-only token in front
+    st.noff16 += (!longOff && off != 0u) ? 2u : 0u;
+    st.noff24 += longOff ? 3u : 0u;
+    if ((st.nseq & (LZ_SEQ_RING - 1u)) == 0) lz_seq_flush(st);
+}
+
+// Wave-parallel LIZv1 encoder (reference lib/lizard_compress_liz.h:43-179) over the sequence list of the sub-block
+// starting at src+S: 64 sequences per step, one per lane.  Four wave prefix sums place every lane's output: bytes
+// in the literals stream, literal source position, and (packed into one scan) tokens / off16 bytes / off24 bytes.
+// Token forms (lizard_decompress_liz.h:1-6): [0_MMMM_LLL] 16-bit offset, [1_MMMM_LLL] repeat offset, 0..31 =
+// 24-bit offset with ml-16 (31 = escape), preceded by a literal-only [1_0000_LLL] when the sequence has literals.
+// Length escapes go to the LITERALS stream (SURVEY finding 4).  Trailing literals are appended raw.
+LZ_DEV void lz_encode_lizv1(const u8* src, u32 S, const LzStreams& st, u8* litOut, u8* flagsOut, u8* off16Out, u8* off24Out)
 {
     const u32 lane = lz_lane();
-    const u32 L = P - anchor, off = P - M;
-    const bool longOff = off >= LZ_16BIT_OFFSET;
-    u32 extLw, extLn, extMw, extMn, token;
-    lz_len_ext(L >= 7u, L - 7u, extLw, extLn);
-    const u32 litTok = L >= 7u ? 7u : L;
-    if (longOff) {                                               // liz.h:96-121
-        const u32 m = ml - LZ_MM_LONGOFF;
-        lz_len_ext(m >= 31u, m - 31u, extMw, extMn);
-        token = m >= 31u ? 31u : m;
-    } else {                                                     // liz.h:122-148
-        lz_len_ext(ml >= 15u, ml - 15u, extMw, extMn);
-        token = litTok | (off == 0 ? 128u : 0u) | ((ml >= 15u ? 15u : ml) << 3);
-    }
-    // literals-stream record: [literal-length escape][literals][match-length escape]
-    const u32 oExtM = extLn + L, R = oExtM + extMn;
-    u8* out = st.lit + st.nlit;
-    for (u32 i = lane; i < R; i += 64u) {
-        u32 b;
-        if (i < extLn)       b = extLw >> (8u * i);
-        else if (i < oExtM)  b = src[anchor + (i - extLn)];
-        else                 b = extMw >> (8u * (i - oExtM));
-        out[i] = (u8)b;
-    }
-    st.nlit += R;
-    if (lane == 0) {
-        u8* f = st.flags + st.nflags;
-        if (longOff) {
-            if (L > 0) { f[0] = (u8)(litTok | 128u); f[1] = (u8)token; }   // literal-only token first, liz.h:83-93
-            else f[0] = (u8)token;
-            lz_st24(st.off24 + st.noff24, off);
-        } else {
-            f[0] = (u8)token;
-            if (off != 0) lz_st16(st.off16 + st.noff16, off);
+    u32 srcPos = S, outPos = 0, fPos = 0, o16Pos = 0, o24Pos = 0;        // uniform carries
+    for (u32 base = 0; base < st.nseq; base += 64u) {
+        const u32 cnt = st.nseq - base < 64u ? st.nseq - base : 64u;
+        u32 L = 0, ml = 0, off = 0, R = 0, adv = 0, packed = 0, tok = 0, litTok = 0;
+        u32 extLw = 0, extLn = 0, extMw = 0, extMn = 0;
+        bool longOff = false;
+        if (lane < cnt) {
+            const u64 q = st.seq[base + lane];
+            L = (u32)q & 0x3FFFFu; ml = (u32)(q >> 18) & 0x3FFFFu; off = (u32)(q >> 36);
+            longOff = off >= LZ_16BIT_OFFSET;
+            litTok = L >= 7u ? 7u : L;
+            lz_len_ext(L >= 7u, L - 7u, extLw, extLn);
+            if (longOff) {                                               // liz.h:96-121
+                const u32 m = ml - LZ_MM_LONGOFF;
+                lz_len_ext(m >= 31u, m - 31u, extMw, extMn);
+                tok = m >= 31u ? 31u : m;
+                packed = (L > 0u ? 2u : 1u) | (3u << 16);
+            } else {                                                     // liz.h:122-148
+                lz_len_ext(ml >= 15u, ml - 15u, extMw, extMn);
+                tok = litTok | (off == 0u ? 128u : 0u) | ((ml >= 15u ? 15u : ml) << 3);
+                packed = 1u | (off != 0u ? 2u << 8 : 0u);
+            }
+            R = extLn + L + extMn; adv = L + ml;
         }
+        const u32 myOut = outPos + lz_wave_scan_excl_add(R);
+        const u32 mySrc = srcPos + lz_wave_scan_excl_add(adv);
+        const u32 pk = lz_wave_scan_excl_add(packed);
+        if (lane < cnt) {
+            u8* f = flagsOut + fPos + (pk & 255u);
+            if (longOff) {
+                if (L > 0u) { f[0] = (u8)(litTok | 128u); f[1] = (u8)tok; } else f[0] = (u8)tok;
+                lz_st24(off24Out + o24Pos + (pk >> 16), off);
+            } else {
+                f[0] = (u8)tok;
+                if (off != 0u) lz_st16(off16Out + o16Pos + ((pk >> 8) & 255u), off);
+            }
+            u8* r = litOut + myOut;
+            for (u32 k = 0; k < extLn; k++) r[k] = (u8)(extLw >> (8u * k));
+            r += extLn + L;
+            for (u32 k = 0; k < extMn; k++) r[k] = (u8)(extMw >> (8u * k));
+        }
+        lz_copy_literal_runs(src, litOut, mySrc, myOut + extLn, L);
+        srcPos = lz_readlane(mySrc + adv, 63u);                          // lanes >= cnt hold zeros
+        outPos = lz_readlane(myOut + R, 63u);
+        const u32 pkEnd = lz_readlane(pk + packed, 63u);
+        fPos += pkEnd & 255u; o16Pos += (pkEnd >> 8) & 255u; o24Pos += pkEnd >> 16;
     }
-    lz_converge();
-    if (longOff) { st.nflags += (L > 0) ? 2u : 1u; st.noff24 += 3u; last_off = off; }
-    else { st.nflags += 1u; if (off != 0) { st.noff16 += 2u; last_off = off; } }
+    lz_copy(litOut + outPos, src + srcPos, st.lastLits);                 // liz.h:168-179
 }
 
 // Sub-block [S,E) of the block at src. windowLog 22 / minMatchLongOff 16 are the level-21/22 values
-// (lizard_common.h:249-250).  table: 2^HASHLOG positions (LZ_EMPTY = never written); tag: 2^TAGLOG bytes.
-// Table: 2^HASHLOG slots of 24 bits (u16 + u8 arrays, LzTab without check bits) holding block-relative
-// positions, LZ_EMPTY24 when never written: 48 KiB of LDS at HASHLOG 14; or the same values in u32 slots
-// (LzTab32) when the table lives in global memory.
-// Positions must stay below 2^24 - 1: blocks up to 16 MiB (the launcher refuses larger ones at these levels).
-#define LZ_EMPTY24 0xFFFFFFu
+// (lizard_common.h:249-250).  table: 2^HASHLOG positions (TAB::kEmpty = never written); tag: 2^TAGLOG bytes of LDS.
+// Positions must stay below TAB::kEmpty (the launcher picks the table form by block size).
 template <int HASHLOG, int TAGLOG, class TAB>
 LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8* tag, LzStreams& st)
 {
@@ -79,9 +157,10 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
     const u64 laneBit = 1ull << lane;
     const u64 lanesBelow = laneBit - 1ull;
     const u32 maxDist = (1u << 22) - 1u;
+    const u32 tagMask = (1u << TAGLOG) - 1u;
     u32 anchor = S;                                              // uniform
     u32 last_off = 0;                                            // uniform; Lizard_initBlock, lizard_compress.c:137
-    if (E - S < LZ_MFLIMIT + 1u) { lz_emit_last_literals(src, anchor, E, st); return; }
+    if (E - S < LZ_MFLIMIT + 1u) { st.lastLits = E - S; st.nlit += E - S; return; }
     const u32 mflimit = E - LZ_MFLIMIT, matchlimit = E - LZ_LASTLITERALS;
     u32 ip = S + 1u;                                             // uniform, pricefast.h:155
     for (;;) {
@@ -92,16 +171,17 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
             const u32 p = ip + lane;
             const bool valid = p < mflimit;
             const u32 lowPos = p > maxDist ? p - maxDist : 0u;   // pricefast.h:11-13, per probe
-            u32 h = 0, e = LZ_EMPTY24, first4 = 0;
-            if (valid) {
-                const u64 bytes = lz_ld64(src + p);
-                first4 = (u32)bytes;
-                h = lz_hash5<HASHLOG>(bytes);
-                e = lz_tab_get(table, h);                        // pricefast.h:160,168 (old value)
-                tag[h & ((1u << TAGLOG) - 1u)] = (u8)lane;
-            }
-            lz_wave_sync();
-            const bool lost = valid && tag[h & ((1u << TAGLOG) - 1u)] != (u8)lane;
+            // source bytes and the repeat-offset candidate: both addresses are known up front
+            const bool repCand = valid && last_off >= LZ_MIN_OFFSET && p >= last_off && p - last_off >= lowPos;   // :19
+            const u64 bytes = lz_ld64(src + (valid ? p : S));
+            const u32 rep4 = lz_ld32(src + (repCand ? p - last_off : S));
+            const u32 first4 = (u32)bytes;
+            const u32 h = lz_hash5<HASHLOG>(bytes);
+            u32 e = table.get(h);                                // pricefast.h:160,168 (old value; garbage when !valid)
+            if (valid) tag[h & tagMask] = (u8)lane;
+            lz_lds_sync();
+            const bool lost = valid && tag[h & tagMask] != (u8)lane;
+            lz_lds_sync();                                       // tag reads done before the next round's writes
             u64 pend = lz_ballot(lost);
             u64 grp = laneBit;
             u32 tAfter = (e >= p || p >= e + LZ_MIN_OFFSET) ? p : e;     // pricefast.h:170-171 when alone in the slot
@@ -120,25 +200,24 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
                 if (mine) grp = g;
                 pend &= ~g;
             }
-            // Lizard_FindMatchFast, pricefast.h:3-87
-            bool rep = false, hashOk = false;
-            if (valid) {
-                if (last_off >= LZ_MIN_OFFSET && p >= last_off && p - last_off >= lowPos)
-                    rep = lz_ld32(src + p - last_off) == first4;                          // :19-31, returns at once
-                if (!rep && e < p && e >= lowPos && p - e >= LZ_MIN_OFFSET && lz_ld32(src + e) == first4) {   // :63-67
-                    if (p - e < LZ_16BIT_OFFSET) hashOk = true;
-                    else                                                                  // :69: needs ml >= minMatchLongOff
-                        hashOk = p + 16u <= matchlimit && lz_ld32(src + p + 4) == lz_ld32(src + e + 4)
-                              && lz_ld64(src + p + 8) == lz_ld64(src + e + 8);
-                }
+            // Lizard_FindMatchFast, pricefast.h:3-87: the repeat offset wins and hides the hash candidate
+            const bool hashCand = valid && e < p && e >= lowPos && p - e >= LZ_MIN_OFFSET;                  // :63-65
+            const u32 c4 = lz_ld32(src + (hashCand ? e : S));
+            const bool rep = repCand && rep4 == first4;                                                     // :19-31
+            bool hashOk = !rep && hashCand && c4 == first4;                                                 // :67
+            const bool needLong = hashOk && p - e >= LZ_16BIT_OFFSET;                                       // :69: needs ml >= minMatchLongOff
+            if (lz_ballot(needLong)) {
+                if (needLong) hashOk = p + 16u <= matchlimit && lz_ld32(src + p + 4) == lz_ld32(src + e + 4)
+                                    && lz_ld64(src + p + 8) == lz_ld64(src + e + 8);
+                lz_converge();
             }
             const u64 okMask = lz_ballot(rep || hashOk);
             const u64 validMask = lz_ballot(valid);
             u32 w = 0;
             u64 commit = validMask;
             if (okMask) { w = lz_ctz64(okMask); commit = validMask & (~0ull >> (63u - w)); }
-            if ((commit & laneBit) && (grp & commit & ~(lanesBelow | laneBit)) == 0) lz_tab_set(table, h, tAfter);
-            lz_wave_sync();
+            if ((commit & laneBit) && (grp & commit & ~(lanesBelow | laneBit)) == 0) table.set(h, tAfter);
+            table.sync();
             if (okMask) {
                 P = lz_readlane(p, w);
                 M = lz_readlane(rep ? p - last_off : e, w);
@@ -146,7 +225,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
             }
             ip += lz_popc64(validMask);                          // "ip++" for every probed position, :173
         }
-        // ---------------- winner: lengths, lazy re-search, encode ----------------
+        // ---------------- winner: lengths, lazy re-search, sequence push ----------------
         LZ_PROF(st, 0);                                          // search rounds
         {
             u32 ml, back0;
@@ -161,7 +240,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
             start2 = ip + ml - 2u;
             {
                 const u32 h2 = lz_hash5<HASHLOG>(lz_ld64(src + start2));
-                const u32 e2 = lz_tab_get(table, h2);
+                const u32 e2 = table.get(h2);
                 const u32 low2 = start2 > maxDist ? start2 - maxDist : 0u;
                 ml2 = 0; back2 = 0;
                 if (e2 < start2 && e2 >= low2 && start2 - e2 >= LZ_MIN_OFFSET) {                            // :106-110
@@ -169,9 +248,9 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
                     lz_count_both(src, start2, e2, matchlimit, ip, mlt, back2);
                     if (mlt >= 4u && (mlt >= LZ_MM_LONGOFF || start2 - e2 < LZ_16BIT_OFFSET)) { ml2 = mlt; ref2 = e2; }   // :112
                 }
-                lz_wave_sync();
-                if (lane == 0 && (e2 >= start2 || start2 >= e2 + LZ_MIN_OFFSET)) lz_tab_set(table, h2, start2);   // :190-191
-                lz_wave_sync();
+                table.sync();
+                if (lane == 0 && (e2 >= start2 || start2 >= e2 + LZ_MIN_OFFSET)) table.set(h2, start2);   // :190-191
+                table.sync();
             }
             LZ_PROF(st, 1);                                      // lazy re-search (table get/set, candidate, count)
             if (!ml2) goto encode;
@@ -187,12 +266,17 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
             }
         encode:
             LZ_PROF(st, 2);
-            lz_emit_lizv1(src, anchor, ip, ml, ref, st, last_off);                        // :231
-            LZ_PROF(st, 3);                                      // LIZv1 encode into the staging areas
+            {
+                const u32 off = ip - ref;                                                 // 0 = repeat (ref == ip), liz.h:122
+                lz_seq_push_liz(st, ip - anchor, ml, off);                                // :231 (encoded later, in parallel)
+                if (off != 0u) last_off = off;                                            // liz.h:119,135
+            }
+            LZ_PROF(st, 3);                                      // sequence push
             ip += ml; anchor = ip;
             if (ml2) { ip = start2; ref = ref2; ml = ml2; ml2 = 0; goto search; }         // :233-238
         }
     }
 tail:
-    lz_emit_last_literals(src, anchor, E, st);
+    if (st.nseq & (LZ_SEQ_RING - 1u)) lz_seq_flush(st);
+    st.lastLits = E - anchor; st.nlit += E - anchor;             // liz.h:168-179
 }

@@ -85,6 +85,12 @@ LZ_DEV u32 lz_popc64(u64 m) { return (u32)__builtin_popcountll(m); }
 // LDS atomics (histograms, bit-string assembly); results unused -> ds_add_u32 / ds_or_b32 without return
 LZ_DEV void lz_lds_atomic_add(u32* p, u32 v) { atomicAdd(p, v); }
 LZ_DEV void lz_lds_atomic_or(u32* p, u32 v) { atomicOr(p, v); }
+// Masked bit-field store into an LDS dword, atomic per lane: *p = (*p & ~mask) | val  (ds_mskor_b32).  Lanes of one
+// instruction may target different fields of the same dword.  val must lie inside mask.
+LZ_DEV void lz_lds_mskor(u32* p, u32 mask, u32 val)
+{
+    asm volatile("ds_mskor_b32 %0, %1, %2" :: "v"((u32)(uintptr_t)p), "v"(mask), "v"(val) : "memory");
+}
 
 // Wave-wide reductions / exclusive prefix sum over all 64 lanes (every lane must call).
 // DPP form (no LDS round trips): Hillis-Steele inside each row of 16 lanes with row_shr:1/2/4/8, then the
@@ -126,4 +132,30 @@ LZ_DEV u64 lz_ld64(const u8* p) { return reinterpret_cast<const lz_u64u*>(p)->v;
 LZ_DEV void lz_st16(u8* p, u32 v) { reinterpret_cast<lz_u16u*>(p)->v = (u16)v; }
 LZ_DEV void lz_st32(u8* p, u32 v) { reinterpret_cast<lz_u32u*>(p)->v = v; }
 LZ_DEV void lz_st64(u8* p, u64 v) { reinterpret_cast<lz_u64u*>(p)->v = v; }
+// One-pass stream traffic (sequence list, the encode pass's literal re-reads, the output streams): with
+// -DLZ_NT_STREAMS these carry the `nt` hint so that they do not displace the hash tables that live in L2.
+#ifdef LZ_NT_STREAMS
+typedef u64 __attribute__((aligned(1))) lz_u64nt;
+typedef u32 __attribute__((aligned(1))) lz_u32nt;
+typedef u16 __attribute__((aligned(1))) lz_u16nt;
+LZ_DEV u64 lz_ld64_s(const u8* p) { return __builtin_nontemporal_load((const lz_u64nt*)p); }
+LZ_DEV u32 lz_ld32_s(const u8* p) { return __builtin_nontemporal_load((const lz_u32nt*)p); }
+LZ_DEV u8  lz_ld8_s(const u8* p) { return __builtin_nontemporal_load(p); }
+LZ_DEV void lz_st64_s(u8* p, u64 v) { __builtin_nontemporal_store(v, (lz_u64nt*)p); }
+LZ_DEV void lz_st32_s(u8* p, u32 v) { __builtin_nontemporal_store(v, (lz_u32nt*)p); }
+LZ_DEV void lz_st16_s(u8* p, u32 v) { __builtin_nontemporal_store((u16)v, (lz_u16nt*)p); }
+LZ_DEV void lz_st8_s(u8* p, u32 v) { __builtin_nontemporal_store((u8)v, p); }
+LZ_DEV u64 lz_ldq_s(const u64* p) { return __builtin_nontemporal_load(p); }
+LZ_DEV void lz_stq_s(u64* p, u64 v) { __builtin_nontemporal_store(v, p); }
+#else
+LZ_DEV u64 lz_ld64_s(const u8* p) { return lz_ld64(p); }
+LZ_DEV u32 lz_ld32_s(const u8* p) { return lz_ld32(p); }
+LZ_DEV u8  lz_ld8_s(const u8* p) { return *p; }
+LZ_DEV void lz_st64_s(u8* p, u64 v) { lz_st64(p, v); }
+LZ_DEV void lz_st32_s(u8* p, u32 v) { lz_st32(p, v); }
+LZ_DEV void lz_st16_s(u8* p, u32 v) { lz_st16(p, v); }
+LZ_DEV void lz_st8_s(u8* p, u32 v) { *p = (u8)v; }
+LZ_DEV u64 lz_ldq_s(const u64* p) { return *p; }
+LZ_DEV void lz_stq_s(u64* p, u64 v) { *p = v; }
+#endif
 #endif  /* LZ_WAVE_H_ */

@@ -4,13 +4,13 @@
 #include "../../lizard_amd/csrc/lz_block.h"
 
 namespace {
-struct Args { const u8* src; u32 n; u8* dst; u32 level; u32* table; u8* tag; u8* scratch; u64* ring; u32 result; bool tab32; };
+struct Args { const u8* src; u32 n; u8* dst; u32 level; u32* table; u8* tag; u8* scratch; u64* ring; u32 result; u32 tabKind; };
 
 template <int PARSER, int HASHLOG, int AUX, bool HUF>
 void entry_block(void* a)
 {
     Args* x = (Args*)a;
-    u32 r = lz_compress_block<PARSER, HASHLOG, AUX, HUF>(x->src, x->n, x->dst, x->level, x->table, x->tag, x->scratch, x->ring, x->tab32);
+    u32 r = lz_compress_block<PARSER, HASHLOG, AUX, HUF>(x->src, x->n, x->dst, x->level, x->table, x->tag, x->scratch, x->ring, x->tabKind);
     if (lz_lane() == 0) x->result = r;
 }
 }  // namespace
@@ -41,7 +41,10 @@ extern "C" int emul_compress_block(const void* src, int n, void* dst, int level,
     if (!hashLog) return -1;
     if (hcLevel && (size_t)n > kHcMaxBlock) return -1;
     a.src = (const u8*)src; a.n = (u32)n; a.dst = (u8*)dst; a.level = (u32)level; a.result = 0;
-    a.tab32 = (base == 21 || base == 22 || base == 10) && (seed & 1u);   // odd seeds run the u32-slot (global-memory) table layout of the mixed-residency kernels
+    // odd seeds run the u32-slot (global-memory) table layout of the mixed-residency kernels; seeds = 2 mod 4 the packed
+    // 18-bit LDS table of the priceFast kernel for blocks up to 256 KiB
+    a.tabKind = ((base == 21 || base == 22 || base == 10) && (seed & 1u)) ? LZ_TABKIND_GLOBAL
+              : (base == 21 && n <= (1 << 18) && (seed & 3u) == 2u) ? LZ_TABKIND_LDS18 : LZ_TABKIND_LDS;
     a.table = (u32*)aligned_alloc(64, (sizeof(u32) << hashLog) + 64);
     a.tag = (u8*)malloc(8192);
     a.scratch = (u8*)malloc(LZ_SCRATCH_BYTES);

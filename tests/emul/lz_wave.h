@@ -113,6 +113,7 @@ LZ_DEV u32 lz_popc64(u64 m) { return (u32)__builtin_popcountll(m); }
 
 LZ_DEV void lz_lds_atomic_add(u32* p, u32 v) { *p += v; }
 LZ_DEV void lz_lds_atomic_or(u32* p, u32 v) { *p |= v; }
+LZ_DEV void lz_lds_mskor(u32* p, u32 mask, u32 val) { *p = (*p & ~mask) | val; }
 
 LZ_DEV u32 lz_wave_reduce_add(u32 v)
 {
@@ -137,4 +138,13 @@ LZ_DEV u64 lz_ld64(const u8* p) { u64 v; memcpy(&v, p, 8); return v; }
 LZ_DEV void lz_st16(u8* p, u32 v) { u16 x = (u16)v; memcpy(p, &x, 2); }
 LZ_DEV void lz_st32(u8* p, u32 v) { memcpy(p, &v, 4); }
 LZ_DEV void lz_st64(u8* p, u64 v) { memcpy(p, &v, 8); }
+LZ_DEV u64 lz_ld64_s(const u8* p) { return lz_ld64(p); }
+LZ_DEV u32 lz_ld32_s(const u8* p) { return lz_ld32(p); }
+LZ_DEV u8  lz_ld8_s(const u8* p) { return *p; }
+LZ_DEV void lz_st64_s(u8* p, u64 v) { lz_st64(p, v); }
+LZ_DEV void lz_st32_s(u8* p, u32 v) { lz_st32(p, v); }
+LZ_DEV void lz_st16_s(u8* p, u32 v) { lz_st16(p, v); }
+LZ_DEV void lz_st8_s(u8* p, u32 v) { *p = (u8)v; }
+LZ_DEV u64 lz_ldq_s(const u64* p) { return *p; }
+LZ_DEV void lz_stq_s(u64* p, u64 v) { *p = v; }
 #endif  /* LZ_WAVE_H_ */

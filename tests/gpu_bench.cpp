@@ -1,0 +1,55 @@
+// tests/gpu_bench.cpp — TEST / MEASUREMENT INFRASTRUCTURE: device-resident timing of the product library through its C ABI,
+// without Python start-up.  One process = one (level, blockSize, nBlocks) configuration:
+//   gpu_bench <level> <blockSize> <nBlocks> [steps=3] [matchProbaPercent=50] [verifyBlocks=16]
+// Input: block b = RDG_genBuffer(blockSize, P, seed b), generated on the device (LizardGPU_datagen_device).
+// Prints the mean kernel time (HIP events inside the library), input GB/s, ratio, and checks `verifyBlocks` blocks spread
+// over the batch against the oracle (oracle/liblizard_oracle.so).  Used for tuning-variant sweeps (LD_LIBRARY_PATH picks
+// the library build) and for the rocprofv3 counter passes (scripts/gpu_traffic.sh).  Exit: 0 ok, 1 mismatch, 2 error.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "lizard_amd.h"
+#include "lizard_oracle.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
+
+int main(int argc, char** argv)
+{
+    if (argc < 4) { fprintf(stderr, "usage: gpu_bench level blockSize nBlocks [steps] [P%%] [verify]\n"); return 2; }
+    const int level = atoi(argv[1]);
+    const size_t bs = strtoull(argv[2], nullptr, 10), nb = strtoull(argv[3], nullptr, 10);
+    const int steps = argc > 4 ? atoi(argv[4]) : 3;
+    const double P = argc > 5 ? atof(argv[5]) / 100.0 : 0.5;
+    const size_t nver = argc > 6 ? strtoull(argv[6], nullptr, 10) : 16;
+    const size_t stride = ((size_t)Lizard_compressBound((int)bs) + 63) & ~(size_t)63;
+    unsigned char *src = nullptr, *dst = nullptr; uint32_t* sizes = nullptr;
+    CK(hipMalloc((void**)&src, nb * bs)); CK(hipMalloc((void**)&dst, nb * stride)); CK(hipMalloc((void**)&sizes, nb * 4));
+    if (LizardGPU_datagen_device(src, nb, bs, P, 0.0, 0, nullptr)) { fprintf(stderr, "datagen: %s\n", LizardGPU_lastError()); return 2; }
+    double ms = 0;
+    for (int s = -1; s < steps; s++) {                       // one untimed warm-up launch
+        int rc = LizardGPU_compressBlocks_device(src, nb, bs, bs, dst, stride, sizes, level, nullptr);
+        if (rc) { fprintf(stderr, "launch: %d %s\n", rc, LizardGPU_lastError()); return 2; }
+        const float k = LizardGPU_lastKernelMs();
+        if (s >= 0) ms += k;
+    }
+    ms /= steps;
+    std::vector<uint32_t> h(nb);
+    CK(hipMemcpy(h.data(), sizes, nb * 4, hipMemcpyDeviceToHost));
+    unsigned long long tot = 0;
+    for (size_t i = 0; i < nb; i++) tot += h[i];
+    int bad = 0;
+    std::vector<unsigned char> blk(bs), got(stride), want(stride);
+    for (size_t k = 0; k < nver && k < nb; k++) {
+        const size_t b = nver > 1 ? k * (nb - 1) / (nver - 1) : 0;
+        CK(hipMemcpy(blk.data(), src + b * bs, bs, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(got.data(), dst + b * stride, h[b], hipMemcpyDeviceToHost));
+        const int r = lzo_compress(blk.data(), want.data(), (int)bs, (int)stride, level);
+        if (r != (int)h[b] || memcmp(got.data(), want.data(), (size_t)r)) { fprintf(stderr, "block %zu differs from the oracle (gpu %u, oracle %d)\n", b, h[b], r); bad++; }
+    }
+    printf("L%d %zu x %zu: kernel %.3f ms  %.2f GB/s input  ratio %.4f  compressed %llu  verify %s\n", level, nb, bs, ms,
+           (double)nb * bs / (ms * 1e-3) / 1e9, (double)nb * bs / (double)tot, tot, bad ? "FAILED" : "ok");
+    return bad ? 1 : 0;
+}

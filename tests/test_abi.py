@@ -120,3 +120,56 @@ def test_reference_cli_runs_on_the_gpu_library(tmp_path):
         assert frame == want, level
         r = subprocess.run([exe, "-d", "-f", str(liz), str(back)], capture_output=True, text=True)
         assert r.returncode == 0 and back.read_bytes() == data
+
+
+@pytest.mark.gpu
+def test_reference_cli_one_byte_tail_block(tmp_path):
+    """A file of k * blockSize + 1 bytes ends in a 1-byte block.  The reference's room test wraps there (maxDstSize 0,
+    lib/lizard_compress.c:238) and the frame layer gets a 6-byte "compressed" block instead of a raw one; the drop-in
+    path must write the same .liz as the stock library (and as LizardGPU_compressFrame)."""
+    exe = os.path.join(util.ROOT, "oracle", "_ref", "lizard_cli_amd")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/lizard_cli_amd not built")
+    for k, extra in ((2, ["-B1"]), (1, ["-B2"]), (0, [])):
+        bs = {"-B1": 128 << 10, "-B2": 256 << 10}.get(extra[0] if extra else "", 4 << 20)
+        data = util.datagen(k * bs + 1, 0.5, 0.0, 23 + k)
+        (tmp_path / "in.bin").write_bytes(data)
+        liz, back = tmp_path / "out.liz", tmp_path / "back.bin"
+        r = subprocess.run([exe, "-10", "-f"] + extra + [str(tmp_path / "in.bin"), str(liz)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        frame = liz.read_bytes()
+        flg, bd = frame[4], frame[5]
+        want = util.compose_frame(data, 10, (bd >> 4) & 7, (flg >> 2) & 1, (flg >> 3) & 1, util.oracle_compress)
+        assert frame == want, k
+        assert frame[-4 - 4 * ((flg >> 2) & 1) - 10:][:4] == bytes([6, 0, 0, 0])        # last block record: LE32 6, not raw
+        r = subprocess.run([exe, "-d", "-f", str(liz), str(back)], capture_output=True, text=True)
+        assert r.returncode == 0 and back.read_bytes() == data
+        # the library's own frame entry agrees
+        from lizard_amd import _lib
+        L = ctypes.CDLL(_lib.LIB_PATH)
+        L.LizardGPU_compressFrameBound.restype = ctypes.c_size_t
+        L.LizardGPU_compressFrameBound.argtypes = [ctypes.c_size_t, ctypes.c_void_p]
+        L.LizardGPU_compressFrame.restype = ctypes.c_size_t
+        L.LizardGPU_compressFrame.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
+        p = util.frame_prefs(10, (bd >> 4) & 7, (flg >> 2) & 1, (flg >> 3) & 1)
+        cap = L.LizardGPU_compressFrameBound(len(data), ctypes.byref(p))
+        dst = ctypes.create_string_buffer(cap)
+        n = L.LizardGPU_compressFrame(dst, cap, data, len(data), ctypes.byref(p))
+        assert dst.raw[:n] == frame, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog,args", [("fuzzer_amd", ["-T10s"]), ("frametest_amd", ["-T10s"])])
+def test_reference_test_programs_on_the_gpu_library(prog, args):
+    """SURVEY.md section 7 step 2 acceptance: the reference's own fuzzer (tests/fuzzer.c: bounds behaviour, limited
+    output, dictionaries, streaming; levels 10 and 17) and frametest (tests/frametest.c: every frame preference,
+    linked and independent blocks, random segmentation; levels 10-49 clamp/dispatch) built by oracle/Makefile against
+    liblizard_amd.so instead of lib/lizard_compress.c.  They check round trips and error behaviour, not bytes; linked
+    mode is served by history-free blocks (include/lizard_amd.h, Lizard_compress_continue)."""
+    exe = os.path.join(util.ROOT, "oracle", "_ref", prog)
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/%s not built" % prog)
+    r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600)
+    tail = (r.stdout + r.stderr)[-2000:]
+    assert r.returncode == 0, tail
+    assert "no CPU fallback" not in r.stderr or prog == "frametest_amd", tail
