@@ -126,12 +126,13 @@ int Lizard_compress_continue(Lizard_stream_t* streamPtr, const char* src, char* 
 {
     int r;
     if (!streamPtr) return 0;
-    if (!LizardGPU_levelSupported(streamPtr->compressionLevel)) { complain("level not implemented on the GPU path", streamPtr->compressionLevel); return 0; }
-    r = lzgpu_compress_one(src, srcSize, dst, maxDstSize, streamPtr->compressionLevel);
-    if (r < 0) { complain("GPU compression failed", streamPtr->compressionLevel); return 0; }
-    if (srcSize > 0) {                                           /* :560-561: contiguous input extends the prefix, anything else starts a new one */
+    if (srcSize > 0) {   /* the reference moves `end` before it compresses (lizard_compress.c:491), so a failed call counts too;
+                            :560-561: contiguous input extends the prefix, anything else starts a new one */
         streamPtr->prefix = (src == streamPtr->end ? streamPtr->prefix : 0) + (size_t)srcSize;
         streamPtr->end = src + srcSize;
     }
+    if (!LizardGPU_levelSupported(streamPtr->compressionLevel)) { complain("level not implemented on the GPU path", streamPtr->compressionLevel); return 0; }
+    r = lzgpu_compress_one(src, srcSize, dst, maxDstSize, streamPtr->compressionLevel);
+    if (r < 0) { complain("GPU compression failed", streamPtr->compressionLevel); return 0; }
     return r;
 }

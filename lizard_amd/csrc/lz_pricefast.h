@@ -180,6 +180,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
             u32 e = table.get(h);                                // pricefast.h:160,168 (old value; garbage when !valid)
             if (valid) tag[h & tagMask] = (u8)lane;
             lz_lds_sync();
+            LZ_PROF(st, 8);                                      // (instrumented build) round: source + repeat bytes, hash, table read
             const bool lost = valid && tag[h & tagMask] != (u8)lane;
             lz_lds_sync();                                       // tag reads done before the next round's writes
             u64 pend = lz_ballot(lost);
@@ -200,6 +201,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
                 if (mine) grp = g;
                 pend &= ~g;
             }
+            LZ_PROF(st, 9);                                      // round: same-slot replay
             // Lizard_FindMatchFast, pricefast.h:3-87: the repeat offset wins and hides the hash candidate
             const bool hashCand = valid && e < p && e >= lowPos && p - e >= LZ_MIN_OFFSET;                  // :63-65
             const u32 c4 = lz_ld32(src + (hashCand ? e : S));
@@ -213,11 +215,13 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
             }
             const u64 okMask = lz_ballot(rep || hashOk);
             const u64 validMask = lz_ballot(valid);
+            LZ_PROF(st, 10);                                     // round: candidate bytes, tests
             u32 w = 0;
             u64 commit = validMask;
             if (okMask) { w = lz_ctz64(okMask); commit = validMask & (~0ull >> (63u - w)); }
             if ((commit & laneBit) && (grp & commit & ~(lanesBelow | laneBit)) == 0) table.set(h, tAfter);
             table.sync();
+            LZ_PROF(st, 11);                                     // round: table put
             if (okMask) {
                 P = lz_readlane(p, w);
                 M = lz_readlane(rep ? p - last_off : e, w);
