@@ -63,11 +63,13 @@ __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
     constexpr u32 kTabWords = (LDSKIND == LZ_TABKIND_LDS18 ? LZ_TAB18_BYTES(HASHLOG) : LZ_TAB_BYTES(HASHLOG)) / 4u + 1u;
     __shared__ u32 ldsTables[NLDS ? NLDS : 1][NLDS ? kTabWords : 1];
     __shared__ Slice lds[W];
-    // fast parser, mixed residency: the global-table waves need the round tag array of LzTabWide; with the Huffman
-    // stage it aliases their workspace, without it they get their own 2 KiB here
-    constexpr bool kMixedFast = PARSER == LZ_PARSER_FAST && NLDS != 0 && NLDS != W;
-    constexpr bool kOwnTags = kMixedFast && !HUF;
-    __shared__ u32 wideTags[kOwnTags ? W - NLDS : 1][kOwnTags ? (1u << LZ_WIDE_TAGLOG) / 4u : 1];
+    // mixed residency: only the global-table waves need a round tag array (LzTabWide / LzTab32; the LDS-table waves find
+    // same-slot lanes through the table itself); with the Huffman stage it aliases their workspace, without it they get
+    // their own here
+    constexpr bool kMixed = PARSER != LZ_PARSER_HASHCHAIN && NLDS != 0 && NLDS != W;
+    constexpr bool kOwnTags = kMixed && !HUF;
+    constexpr u32 kTagWords = (PARSER == LZ_PARSER_FAST ? (1u << LZ_WIDE_TAGLOG) : (1u << AUX)) / 4u;
+    __shared__ u32 wideTags[kOwnTags ? W - NLDS : 1][kOwnTags ? kTagWords : 1];
     const u32 wave = lz_uniform(threadIdx.x >> 6);               // readfirstlane: the wave index (and everything derived from it) lives in SGPRs
     Slice& my = lds[wave];
     const u64 slot = (u64)blockIdx.x * LZ_MAX_WAVES + wave;
@@ -78,6 +80,9 @@ __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
     else tableMem = wave < (u32)NLDS ? (void*)ldsTables[wave] : (void*)(a.tables + slot * a.tableStride);
     const u32 tabKind = (NLDS != W && wave >= (u32)NLDS) ? LZ_TABKIND_GLOBAL : LDSKIND;
     u8* const ws = (kOwnTags && tabKind == LZ_TABKIND_GLOBAL) ? (u8*)wideTags[kOwnTags ? wave - NLDS : 0] : (u8*)my.ws;
+#ifdef LZ_LDS_PRIO
+    if (tabKind != LZ_TABKIND_GLOBAL) __builtin_amdgcn_s_setprio(LZ_LDS_PRIO);   // the LDS-table waves are the fast ones: they issue first
+#endif
     for (;;) {
         lz_converge();
         const u32 b = lz_claim_index(a.counter);
@@ -131,8 +136,9 @@ __global__ __launch_bounds__(64 * LZ_WAVES_HC) void lz_hashchain_kernel(LzBatch 
 //   general (blocks < 16 MiB): 24-bit positions, 48 KiB (LzTabPf24) — two tables per CU (one at level 41).
 // The remaining waves of the workgroup keep u32 slots in their 64 KiB global-memory slot (LzTab32).
 #ifndef LZ_PF_W
-#define LZ_PF_W 16
+#define LZ_PF_W 12
 #endif
+#define LZ_PF22_W 16
 #ifndef LZ_PF_NLDS
 #define LZ_PF_NLDS 2
 #endif
@@ -143,16 +149,16 @@ __global__ __launch_bounds__(64 * LZ_WAVES_HC) void lz_hashchain_kernel(LzBatch 
 #define LZ_PF_TAGLOG 11
 #endif
 #ifndef LZ_PF18_W
-#define LZ_PF18_W 16
+#define LZ_PF18_W 10
 #endif
 #ifndef LZ_PF18_NLDS
 #define LZ_PF18_NLDS 4
 #endif
 #ifndef LZ_PF18_TAGLOG
-#define LZ_PF18_TAGLOG 9
+#define LZ_PF18_TAGLOG 11
 #endif
 #ifndef LZ_PF18_W_HUF
-#define LZ_PF18_W_HUF 15
+#define LZ_PF18_W_HUF 12
 #endif
 #ifndef LZ_PF18_NLDS_HUF
 #define LZ_PF18_NLDS_HUF 2
@@ -163,17 +169,17 @@ __global__ __launch_bounds__(64 * (SMALL ? (HUF ? LZ_PF18_W_HUF : LZ_PF18_W) : L
 {
     if constexpr (SMALL)
         lz_wave_main<LZ_PARSER_PRICEFAST, 14, (HUF ? 11 : LZ_PF18_TAGLOG), HUF, (HUF ? LZ_PF18_W_HUF : LZ_PF18_W),
-                     (HUF ? LZ_HUF_WS_WORDS : (1u << LZ_PF18_TAGLOG) / 4u), (HUF ? LZ_PF18_NLDS_HUF : LZ_PF18_NLDS), LZ_TABKIND_LDS18>(a);
+                     (HUF ? LZ_HUF_WS_WORDS : 1), (HUF ? LZ_PF18_NLDS_HUF : LZ_PF18_NLDS), LZ_TABKIND_LDS18>(a);
     else
-        lz_wave_main<LZ_PARSER_PRICEFAST, 14, LZ_PF_TAGLOG, HUF, LZ_PF_W, (HUF ? LZ_HUF_WS_WORDS : (1u << LZ_PF_TAGLOG) / 4u),
+        lz_wave_main<LZ_PARSER_PRICEFAST, 14, LZ_PF_TAGLOG, HUF, LZ_PF_W, (HUF ? LZ_HUF_WS_WORDS : 1),
                      (HUF ? LZ_PF_NLDS_HUF : LZ_PF_NLDS)>(a);
 }
 
 // levels 22 / 42: priceFast + LIZv1 with a 2^18-slot table: 1 MiB of u32 slots per wave, all in global memory
 template <bool HUF>
-__global__ __launch_bounds__(64 * LZ_PF_W) void lz_pricefast18_kernel(LzBatch a)
+__global__ __launch_bounds__(64 * LZ_PF22_W) void lz_pricefast18_kernel(LzBatch a)
 {
-    lz_wave_main<LZ_PARSER_PRICEFAST, 18, LZ_PF_TAGLOG, HUF, LZ_PF_W, (HUF ? LZ_HUF_WS_WORDS : (1u << LZ_PF_TAGLOG) / 4u), 0>(a);
+    lz_wave_main<LZ_PARSER_PRICEFAST, 18, LZ_PF_TAGLOG, HUF, LZ_PF22_W, (HUF ? LZ_HUF_WS_WORDS : (1u << LZ_PF_TAGLOG) / 4u), 0>(a);
 }
 
 // synthetic input: one thread per block, block b = RDG_genBuffer(blockSize, P, seed0 + b)
@@ -403,7 +409,7 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
     else if (lv == 11 || lv == 31) W = LZ_WAVES_FAST18;
     else if (hcLevel)              W = LZ_WAVES_HC;
     else if (lv == 21 || lv == 41) W = pfSmall ? (huf ? LZ_PF18_W_HUF : LZ_PF18_W) : LZ_PF_W;
-    else                           W = LZ_PF_W;
+    else                           W = LZ_PF22_W;
     if (hcLevel) {
         const size_t cap = (blockSize + 65535u) & ~(size_t)65535u;
         if (!c.hcSlots || c.hcMaxBlock < cap) {

@@ -44,6 +44,9 @@
 struct LzTabPf24 {
     u16* lo; u8* hi;
     static constexpr u32 kEmpty = LZ_EMPTY24;
+    static constexpr bool kSpecPut = true;
+    LZ_DEVM void specPut(u32 h, u32 p) const { lo[h] = (u16)p; }
+    LZ_DEVM bool specLost(u32 h, u32 p) const { return lo[h] != (u16)p; }
     LZ_DEVM u32  get(u32 h) const { return (u32)lo[h] | ((u32)hi[h] << 16); }
     LZ_DEVM void set(u32 h, u32 v) const { lo[h] = (u16)v; hi[h] = (u8)(v >> 16); }
     LZ_DEVM void sync() const { lz_lds_sync(); }
@@ -51,6 +54,9 @@ struct LzTabPf24 {
 struct LzTab18 {
     u16* lo; u32* hi;
     static constexpr u32 kEmpty = LZ_EMPTY18;
+    static constexpr bool kSpecPut = true;
+    LZ_DEVM void specPut(u32 h, u32 p) const { lo[h] = (u16)p; }
+    LZ_DEVM bool specLost(u32 h, u32 p) const { return lo[h] != (u16)p; }
     LZ_DEVM u32  get(u32 h) const { return (u32)lo[h] | (((hi[h >> 4] >> (2u * (h & 15u))) & 3u) << 16); }
     LZ_DEVM void set(u32 h, u32 v) const { lo[h] = (u16)v; lz_lds_mskor(&hi[h >> 4], 3u << (2u * (h & 15u)), (v >> 16) << (2u * (h & 15u))); }
     LZ_DEVM void sync() const { lz_lds_sync(); }
@@ -59,6 +65,9 @@ struct LzTab18 {
 struct LzTab32 {
     u32* w;
     static constexpr u32 kEmpty = LZ_EMPTY24;
+    static constexpr bool kSpecPut = false;
+    LZ_DEVM void specPut(u32, u32) const {}
+    LZ_DEVM bool specLost(u32, u32) const { return false; }
     LZ_DEVM u32  get(u32 h) const { return w[h]; }
     LZ_DEVM void set(u32 h, u32 v) const { w[h] = v; }
     LZ_DEVM void sync() const { lz_wave_sync(); }
@@ -163,6 +172,11 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
     if (E - S < LZ_MFLIMIT + 1u) { st.lastLits = E - S; st.nlit += E - S; return; }
     const u32 mflimit = E - LZ_MFLIMIT, matchlimit = E - LZ_LASTLITERALS;
     u32 ip = S + 1u;                                             // uniform, pricefast.h:155
+    // First round after a sequence: its loads are issued as soon as the sequence's forward length is known, for the
+    // position the parse continues at if the lazy step does not find a second match (the common case); checked at use.
+    bool havePre = false;                                        // uniform
+    u32 preIp = 0, preOff = 0;                                   // uniform: the prediction
+    u64 preBytes = 0; u32 preRep4 = 0;
     for (;;) {
         // ---------------- search: 64 consecutive positions per round ----------------
         u32 P = 0, M = 0;
@@ -173,16 +187,32 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
             const u32 lowPos = p > maxDist ? p - maxDist : 0u;   // pricefast.h:11-13, per probe
             // source bytes and the repeat-offset candidate: both addresses are known up front
             const bool repCand = valid && last_off >= LZ_MIN_OFFSET && p >= last_off && p - last_off >= lowPos;   // :19
-            const u64 bytes = lz_ld64(src + (valid ? p : S));
-            const u32 rep4 = lz_ld32(src + (repCand ? p - last_off : S));
+            u64 bytes; u32 rep4;
+            if (havePre && ip == preIp && last_off == preOff) { bytes = preBytes; rep4 = preRep4; }
+            else { bytes = lz_ld64(src + (valid ? p : S)); rep4 = lz_ld32(src + (repCand ? p - last_off : S)); }
+            havePre = false;
             const u32 first4 = (u32)bytes;
             const u32 h = lz_hash5<HASHLOG>(bytes);
             u32 e = table.get(h);                                // pricefast.h:160,168 (old value; garbage when !valid)
-            if (valid) tag[h & tagMask] = (u8)lane;
-            lz_lds_sync();
+            // Which lanes of this round share a table slot?  LDS tables: every lane stores the low half of its position
+            // speculatively and reads the slot back — a lane that does not find its own value shares the slot with a later
+            // lane (positions of a round differ by < 2^16); exact, no extra memory, settled after the winner is known.
+            // Global tables: nothing is stored before the winner is known; lanes meet in a small LDS tag array (false
+            // alarms only cost a turn of the replay loop).
+            bool lost;
+            if constexpr (TAB::kSpecPut) {
+                lz_lds_sync();                                   // every lane has read before any lane stores
+                if (valid) table.specPut(h, p);
+                lz_lds_sync();
+                lost = valid && table.specLost(h, p);
+            } else {
+                if (valid) tag[h & tagMask] = (u8)lane;
+                lz_lds_sync();
+                lost = valid && tag[h & tagMask] != (u8)lane;
+                lz_lds_sync();                                   // tag reads done before the next round's writes
+            }
             LZ_PROF(st, 8);                                      // (instrumented build) round: source + repeat bytes, hash, table read
-            const bool lost = valid && tag[h & tagMask] != (u8)lane;
-            lz_lds_sync();                                       // tag reads done before the next round's writes
+            const u32 eOld = e;
             u64 pend = lz_ballot(lost);
             u64 grp = laneBit;
             u32 tAfter = (e >= p || p >= e + LZ_MIN_OFFSET) ? p : e;     // pricefast.h:170-171 when alone in the slot
@@ -219,7 +249,15 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
             u32 w = 0;
             u64 commit = validMask;
             if (okMask) { w = lz_ctz64(okMask); commit = validMask & (~0ull >> (63u - w)); }
-            if ((commit & laneBit) && (grp & commit & ~(lanesBelow | laneBit)) == 0) table.set(h, tAfter);
+            if constexpr (TAB::kSpecPut) {
+                // settle: the last committed lane of every slot group stores the slot's final value; a group none of whose
+                // lanes happened (all after the winner) is restored by its first lane (whose `e` is still the old value)
+                const u64 c = grp & commit;
+                const bool writer = valid && (c ? (c >> lane) == 1ull : (grp & lanesBelow) == 0);
+                if (writer) table.set(h, c ? tAfter : eOld);
+            } else {
+                if ((commit & laneBit) && (grp & commit & ~(lanesBelow | laneBit)) == 0) table.set(h, tAfter);
+            }
             table.sync();
             LZ_PROF(st, 11);                                     // round: table put
             if (okMask) {
@@ -233,7 +271,31 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
         LZ_PROF(st, 0);                                          // search rounds
         {
             u32 ml, back0;
+            // The lazy step will look at start2 = P + (forward length) - 2 (:187).  The forward length is not known yet, but
+            // it is usually short: lane j prepares the lookup for length 4 + j — source bytes, hash, table slot — while the
+            // winner's own lengths are being measured, so that the lazy step starts with its candidate already in hand.
+            // (The table is in its final state for this round: the lookup of :188 happens after the puts of :170-171.)
+            // Only where a table read is an LDS access: in global memory 64 speculative slots per sequence are 64 more sectors.
+            constexpr bool kSpecLazy = TAB::kSpecPut;
+            const u32 qSpec = P + 2u + lane;
+            u64 bSpec = 0;
+            if constexpr (kSpecLazy) bSpec = lz_ld64(src + (qSpec + 8u <= E ? qSpec : S));
             lz_count_both(src, P, M, matchlimit, anchor, ml, back0);                      // both lengths, one round trip
+            u32 hSpec = 0, eSpec = 0;
+            if constexpr (kSpecLazy) { hSpec = lz_hash5<HASHLOG>(bSpec); eSpec = table.get(hSpec); }
+            {   // loads of the next round, should the parse continue right behind this match with this offset
+                const u32 offP = P - M;                          // (a repeat match leaves last_off as it is: P - M == last_off then)
+                preIp = P + ml; preOff = offP;
+                const u32 pp = preIp + lane;
+                const bool pv = pp < mflimit;
+                const u32 plow = pp > maxDist ? pp - maxDist : 0u;
+                const bool prc = pv && offP >= LZ_MIN_OFFSET && pp >= offP && pp - offP >= plow;
+                preBytes = lz_ld64(src + (pv ? pp : S));
+                preRep4 = lz_ld32(src + (prc ? pp - offP : S));
+                havePre = true;
+            }
+            const u32 specIdx = ml - 4u;                                                  // lane that guessed right (if < 64)
+            bool useSpec = kSpecLazy && specIdx < 64u && P + ml - 2u + 8u <= E;
             u32 ml2 = 0, start2 = 0, ref2 = 0, ref = M, back2 = 0;
             ip = P;
             if (ip - ref == last_off) { ref = ip; goto encode; }                          // :174 -> repeat offset, no lazy step
@@ -243,8 +305,10 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
             if (ip + ml >= mflimit) goto encode;                                          // :185
             start2 = ip + ml - 2u;
             {
-                const u32 h2 = lz_hash5<HASHLOG>(lz_ld64(src + start2));
-                const u32 e2 = table.get(h2);
+                u32 h2, e2;
+                if (useSpec) { h2 = lz_readlane(hSpec, specIdx); e2 = lz_readlane(eSpec, specIdx); }
+                else { h2 = lz_hash5<HASHLOG>(lz_ld64(src + start2)); e2 = table.get(h2); }
+                useSpec = false;                                                          // later passes look elsewhere
                 const u32 low2 = start2 > maxDist ? start2 - maxDist : 0u;
                 ml2 = 0; back2 = 0;
                 if (e2 < start2 && e2 >= low2 && start2 - e2 >= LZ_MIN_OFFSET) {                            // :106-110
