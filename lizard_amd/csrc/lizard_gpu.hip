@@ -49,14 +49,17 @@ struct LzBatch {
 #define LZ_WAVES_FAST_HUF  16
 #endif
 #ifndef LZ_NLDS_FAST_HUF
-#define LZ_NLDS_FAST_HUF   5
+#define LZ_NLDS_FAST_HUF   11
+#endif
+#ifndef LZ_HUF_POOL
+#define LZ_HUF_POOL        5              // Huffman workspaces shared by the 16 waves of a level-30 workgroup (0 = one each)
 #endif
 #define LZ_WAVES_FASTLDS      13             // all tables in LDS (blocks above 4 MiB)
-#define LZ_WAVES_FASTLDS_HUF  9
+#define LZ_WAVES_FASTLDS_HUF  11
 #define LZ_MAX_WAVES          16             // scratch / table slots per CU
 
 // NLDS of the W waves keep their hash table in LDS (form LDSKIND), the others in the wave's global-memory slot.
-template <int PARSER, int HASHLOG, int AUX, bool HUF, int W, int WSWORDS, int NLDS = (HASHLOG > 14 ? 0 : W), u32 LDSKIND = LZ_TABKIND_LDS>
+template <int PARSER, int HASHLOG, int AUX, bool HUF, int W, int WSWORDS, int NLDS = (HASHLOG > 14 ? 0 : W), u32 LDSKIND = LZ_TABKIND_LDS, int POOL = 0>
 __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
 {
     struct Slice { u64 ring[LZ_SEQ_RING]; u32 ws[WSWORDS]; };
@@ -67,7 +70,11 @@ __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
     // same-slot lanes through the table itself); with the Huffman stage it aliases their workspace, without it they get
     // their own here
     constexpr bool kMixed = PARSER != LZ_PARSER_HASHCHAIN && NLDS != 0 && NLDS != W;
-    constexpr bool kOwnTags = kMixed && !HUF;
+    constexpr bool kOwnTags = kMixed && (!HUF || POOL != 0);
+    // POOL != 0: the waves borrow their Huffman workspace from a pool of POOL slots (lz_pool_acquire) instead of owning one
+    __shared__ u32 hufPool[POOL ? POOL : 1][POOL ? LZ_HUF_WS_WORDS : 1];
+    __shared__ u32 hufPoolMask;
+    if constexpr (POOL != 0) { if (threadIdx.x == 0) hufPoolMask = 0; __syncthreads(); }
     constexpr u32 kTagWords = (PARSER == LZ_PARSER_FAST ? (1u << LZ_WIDE_TAGLOG) : (1u << AUX)) / 4u;
     __shared__ u32 wideTags[kOwnTags ? W - NLDS : 1][kOwnTags ? kTagWords : 1];
     const u32 wave = lz_uniform(threadIdx.x >> 6);               // readfirstlane: the wave index (and everything derived from it) lives in SGPRs
@@ -89,7 +96,8 @@ __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
         if (b >= a.nBlocks) break;
         const u32 n = (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
         const u32 c = lz_compress_block<PARSER, HASHLOG, AUX, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
-                                                                  a.level, tableMem, ws, scratch, my.ring, tabKind);
+                                                                  a.level, tableMem, ws, scratch, my.ring, tabKind,
+                                                                  POOL ? &hufPool[0][0] : nullptr, POOL ? &hufPoolMask : nullptr, (u32)POOL);
         if (lz_lane() == 0) a.sizes[b] = c;
         lz_converge();
     }
@@ -104,8 +112,8 @@ __global__ __launch_bounds__(64 * (MIXED ? (HUF ? LZ_WAVES_FAST_HUF : LZ_WAVES_F
 void lz_fast12_kernel(LzBatch a)
 {
     if constexpr (MIXED)
-        lz_wave_main<LZ_PARSER_FAST, 12, 0, HUF, (HUF ? LZ_WAVES_FAST_HUF : LZ_WAVES_FAST), (HUF ? LZ_HUF_WS_WORDS : 1),
-                     (HUF ? LZ_NLDS_FAST_HUF : LZ_NLDS_FAST)>(a);
+        lz_wave_main<LZ_PARSER_FAST, 12, 0, HUF, (HUF ? LZ_WAVES_FAST_HUF : LZ_WAVES_FAST), (HUF && !LZ_HUF_POOL ? LZ_HUF_WS_WORDS : 1),
+                     (HUF ? LZ_NLDS_FAST_HUF : LZ_NLDS_FAST), LZ_TABKIND_LDS, (HUF ? LZ_HUF_POOL : 0)>(a);
     else
         lz_wave_main<LZ_PARSER_FAST, 12, 0, HUF, (HUF ? LZ_WAVES_FASTLDS_HUF : LZ_WAVES_FASTLDS), (HUF ? LZ_HUF_WS_WORDS : 1),
                      (HUF ? LZ_WAVES_FASTLDS_HUF : LZ_WAVES_FASTLDS)>(a);
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(64 * LZ_WAVES_HC) void lz_hashchain_kernel(LzBatch 
 #define LZ_PF_NLDS 2
 #endif
 #ifndef LZ_PF_NLDS_HUF
-#define LZ_PF_NLDS_HUF 1
+#define LZ_PF_NLDS_HUF 2
 #endif
 #ifndef LZ_PF_TAGLOG
 #define LZ_PF_TAGLOG 11
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(64 * LZ_WAVES_HC) void lz_hashchain_kernel(LzBatch 
 #define LZ_PF18_W_HUF 12
 #endif
 #ifndef LZ_PF18_NLDS_HUF
-#define LZ_PF18_NLDS_HUF 2
+#define LZ_PF18_NLDS_HUF 3
 #endif
 #define LZ_PF_SLOT_BYTES 65536u
 template <bool HUF, bool SMALL>

@@ -548,6 +548,33 @@ LZ_DEV void lz_st24(u8* p, u32 v) { p[0] = (u8)v; p[1] = (u8)(v >> 8); p[2] = (u
 
 // ---- sub-block container (reference lib/lizard_compress.c:141-250) -------------------------------
 
+// Huffman workspace pool of a workgroup.  A wave needs its LZ_HUF_WS_WORDS of LDS only while it entropy-codes a sub-block
+// (about a third of its time at level 30), so the W waves of a workgroup share K < W workspaces and the LDS this frees
+// holds more hash tables.  A wave holding a workspace never waits for anything else: no deadlock; waves that find the pool
+// empty sleep and poll.  mask == nullptr: the wave owns `base` outright.
+struct LzHufPool { u32* base; u32* mask; u32 count; };
+LZ_DEV u32* lz_pool_acquire(const LzHufPool& pool, u32& slot)
+{
+    slot = 0;
+    if (!pool.mask) return pool.base;
+    for (;;) {
+        lz_converge();
+        const u32 freeBits = ~lz_uniform(lz_lds_poll(pool.mask)) & ((1u << pool.count) - 1u);
+        if (freeBits) {
+            const u32 bit = freeBits & (0u - freeBits);
+            const u32 old = lz_readlane(lz_lds_atomic_or_rtn(pool.mask, lz_lane() == 0 ? bit : 0u), 0);   // branch-free claim, like lz_claim_index
+            if (!(old & bit)) { slot = bit; lz_lds_sync(); return pool.base + (31u - (u32)__builtin_clz(bit)) * LZ_HUF_WS_WORDS; }
+        } else lz_sleep();
+    }
+}
+LZ_DEV void lz_pool_release(const LzHufPool& pool, u32 slot)
+{
+    if (!pool.mask) return;
+    lz_lds_sync();                                               // my last workspace accesses are done
+    lz_lds_atomic_and(pool.mask, lz_lane() == 0 ? ~slot : 0xFFFFFFFFu);
+    lz_converge();
+}
+
 // Lizard_writeBlock (reference lib/lizard_compress.c:186-250) over the sequence list of one sub-block.  The stream
 // sizes are known from the parse, so the raw-fallback rule of :201 is decided before a single output byte exists;
 // without Huffman also :228, and every stream is encoded straight into its final place in dst (order: len (always
@@ -556,7 +583,7 @@ LZ_DEV void lz_st24(u8* p, u32 v) { p[0] = (u8)v; p[1] = (u8)(v >> 8); p[2] = (u
 // stage needs them contiguous); the offset streams still go straight to dst.  LIZ: LIZv1 codewords (priceFast),
 // else fastLZ4 codewords (whose off16/off24 streams are always empty).
 template <bool HUF, bool LIZ>
-LZ_DEV u32 lz_write_subblock_seq(const u8* src, u32 S, u32 E, u8* op, LzStreams& st, u32* ws)
+LZ_DEV u32 lz_write_subblock_seq(const u8* src, u32 S, u32 E, u8* op, LzStreams& st, const LzHufPool& pool)
 {
     const u32 n = E - S, sum = st.nflags + st.nlit + st.noff16 + st.noff24;
     bool raw = st.nlit < LZ_LASTLITERALS || sum + 16u > n;             // lizard_compress.c:201
@@ -579,10 +606,12 @@ LZ_DEV u32 lz_write_subblock_seq(const u8* src, u32 S, u32 E, u8* op, LzStreams&
             if constexpr (LIZ) lz_encode_lizv1(src, S, st, st.lit, st.flags, p16 + 3u, p24 + 3u);
             else               lz_encode_lz4(src, S, st, st.lit, st.flags);
             lz_wave_sync();
-            u32 hf = 0, hl = 0;
+            u32 hf = 0, hl = 0, slot;
             u8* q = pf;
+            u32* const ws = lz_pool_acquire(pool, slot);                                // held for the entropy stage only
             q += lz_put_stream_huf(q, st.flags, st.nflags, ws, &hf LZ_HPROF_ARG(st));   // LIZARD_FLAG_FLAGS = 2
             q += lz_put_stream_huf(q, st.lit, st.nlit, ws, &hl LZ_HPROF_ARG(st));       // LIZARD_FLAG_LITERALS = 1
+            lz_pool_release(pool, slot);
             total = (u32)(q - op);
             if (lz_lane() == 0) op[0] = (u8)(hl * 1u + hf * 2u);
             lz_converge();
@@ -620,7 +649,7 @@ LZ_DEV u32 lz_write_subblock_seq(const u8* src, u32 S, u32 E, u8* op, LzStreams&
 #define LZ_TABKIND_LDS18    2u
 template <int PARSER, int HASHLOG, int AUX, bool HUF>
 LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tableMem, u8* ws, u8* scratch, u64* seqRing,
-                             u32 tabKind = LZ_TABKIND_LDS)
+                             u32 tabKind = LZ_TABKIND_LDS, u32* hufPoolBase = nullptr, u32* hufPoolMask = nullptr, u32 hufPoolCount = 0)
 {
     const u32 lane = lz_lane();
     LzStreams st;
@@ -669,7 +698,10 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
         else if (tabKind == LZ_TABKIND_GLOBAL) lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, pf32, ws, st);
         else if (tabKind == LZ_TABKIND_LDS18)  lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, pf18, ws, st);
         else                                   lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, pf24, ws, st);
-        op += lz_write_subblock_seq<HUF, kLiz>(src, pos, pos + part, dst + op, st, (u32*)ws);
+        {   // Huffman workspace: the wave's own (it doubles as the parser's tag array), or one borrowed from the workgroup's pool
+            LzHufPool pool; pool.base = hufPoolMask ? hufPoolBase : (u32*)ws; pool.mask = hufPoolMask; pool.count = hufPoolCount;
+            op += lz_write_subblock_seq<HUF, kLiz>(src, pos, pos + part, dst + op, st, pool);
+        }
         LZ_PROF(st, 5);                                       // container: encode pass / Huffman
         lz_wave_sync();                                       // scratch is reused by the next sub-block
         LZ_PROF(st, 4);                                       // draining the sub-block's stores

@@ -32,17 +32,13 @@
 #define LZ_HUF_MAXBITS     12u    // HUF_TABLELOG_MAX, huf.h:118
 #define LZ_HUF_DEFAULTLOG  11u    // HUF_TABLELOG_DEFAULT, huf.h:119
 
-// LDS workspace (u32 words). The node area and the packer's staging ring alias (disjoint in time).
-#define LZ_HUF_WS_COUNT    0u                          // u32 count[256]; after the sort: weights (bytes 0..255) and,
-#define LZ_HUF_WS_FSE      96u                         //   from word 96 on, 160 words of FSE tables for the weight header
-#define LZ_HUF_WS_CTAB     256u                        // u16 ctab[256]: val | nbBits << 12
-#define LZ_HUF_WS_NODECNT  384u                        // u32 nodeCount[1 + 512] (slot 0 = barrier node -1)
-#define LZ_HUF_WS_PARENT   (LZ_HUF_WS_NODECNT + 514u)  // u16 parent[512]
-#define LZ_HUF_WS_BYTE     (LZ_HUF_WS_PARENT + 256u)   // u8 byte[256] (leaves only)
-#define LZ_HUF_WS_NBITS    (LZ_HUF_WS_BYTE + 64u)      // u8 nbBits[512]
-#define LZ_HUF_WS_WORDS    (LZ_HUF_WS_NBITS + 128u)    // 1346 words = 5384 B
-#define LZ_HUF_WS_STAGE    LZ_HUF_WS_NODECNT           // packer staging ring (>= 100 words), aliases nodes
+// LDS workspace (u32 words): 2 KiB per wave.  Only the wave-parallel steps use it (histogram, sort scatter, the two
+// index exchanges, the code table, the packer's ring); everything serial lives in registers (see LzV64 / LzV256).
+#define LZ_HUF_WS_COUNT    0u                          // u32[256]: histogram -> sort scatter -> depth / code-length exchange
+#define LZ_HUF_WS_CTAB     256u                        // u16[256]: val | nbBits << 12
+#define LZ_HUF_WS_STAGE    384u                        // packer staging ring
 #define LZ_HUF_STAGE_WORDS 104u
+#define LZ_HUF_WS_WORDS    512u                        // (the parser's 2 KiB round tag array aliases it)
 
 LZ_DEV u32 lz_highbit(u32 v) { return 31u - (u32)__builtin_clz(v); }   // BIT_highbit32, v != 0
 
@@ -60,240 +56,284 @@ LZ_DEV u32 lz_fse_optimal_tablelog(u32 maxTableLog, u32 srcSize, u32 maxSym, u32
     return tl;
 }
 
-// ---- single-lane LSB-first bit writer into global memory (weight header only; tiny) ----
-struct LzBitW { u8* p; u32 pos; u64 acc; u32 nb; };
-LZ_DEV void lz_bw_add(LzBitW& b, u32 v, u32 n)
-{
-    if (n == 0) return;
-    b.acc |= (u64)(v & (u32)((1ull << n) - 1ull)) << b.nb;
-    b.nb += n;
-    while (b.nb >= 8u) { b.p[b.pos++] = (u8)b.acc; b.acc >>= 8; b.nb -= 8u; }
-}
-LZ_DEV u32 lz_bw_finish(LzBitW& b) { if (b.nb) { b.p[b.pos++] = (u8)b.acc; b.acc = 0; b.nb = 0; } return b.pos; }
+// ---- tables in registers --------------------------------------------------------------------------------------
+// The tree build, the depth limit, the FSE weight header: <= 256 symbols, integer, every step depends on the one before.
+// The reference runs them on one core with its tables in L1; one lane with tables in LDS pays ~130 clocks per
+// dependent access.  Here they run as WAVE-UNIFORM code — every lane executes the same scalar control flow, loop
+// counters and accumulators live in SGPRs — on tables spread over the lanes of a VGPR: entry i of a 64-entry table is
+// lane i of one register (v_readlane / v_writelane with a scalar index, a few clocks, no memory), a 256-entry table is
+// four such registers.  Indices and stored values must be wave-uniform.
+struct LzV64 {
+    u32 r;
+    LZ_DEVM u32  get(u32 i) const { return lz_readlane(r, i); }
+    LZ_DEVM void set(u32 i, u32 x) { r = lz_writelane(r, x, i); }
+};
+struct LzV256 {
+    u32 r0, r1, r2, r3;
+    // branch-free: four independent v_readlane and a scalar select (a 4-way branch costs more than the three spare reads)
+    LZ_DEVM u32 get(u32 i) const
+    {
+        const u32 l = i & 63u, c = i >> 6;
+        const u32 a = lz_readlane(r0, l), b = lz_readlane(r1, l), d = lz_readlane(r2, l), e = lz_readlane(r3, l);
+        return c == 0 ? a : c == 1 ? b : c == 2 ? d : e;
+    }
+    LZ_DEVM void set(u32 i, u32 x)
+    {
+        const u32 l = i & 63u, c = i >> 6;
+        r0 = lz_writelane(r0, x, c == 0 ? l : 64u); r1 = lz_writelane(r1, x, c == 1 ? l : 64u);
+        r2 = lz_writelane(r2, x, c == 2 ? l : 64u); r3 = lz_writelane(r3, x, c == 3 ? l : 64u);
+    }
+};
 
-// HUF_setMaxHeight, huf_compress.c:223-297 (lane 0 only). nodeCnt/nbits index the sorted leaves 0..last.
-LZ_DEV u32 lz_huf_set_max_height(const u32* nodeCnt, u8* nbits, u32 lastNonNull, u32 maxNbBits)
+// LSB-first bit writer whose output is a register table of 64 dwords (the weight header is < 256 bytes)
+struct LzBitV { LzV64 out; u64 acc; u32 nb, words; };
+LZ_DEV void lz_bv_init(LzBitV& b) { b.out.r = 0; b.acc = 0; b.nb = 0; b.words = 0; }
+LZ_DEV void lz_bv_flush(LzBitV& b) { if (b.nb >= 32u) { b.out.set(b.words & 63u, (u32)b.acc); b.words++; b.acc >>= 32; b.nb -= 32u; } }
+LZ_DEV void lz_bv_add(LzBitV& b, u32 v, u32 n)                  // n <= 16
 {
-    const u32 largestBits = nbits[lastNonNull];
+    b.acc |= (u64)(v & ((1u << n) - 1u)) << b.nb;
+    b.nb += n;
+    lz_bv_flush(b);
+}
+LZ_DEV void lz_bv_align(LzBitV& b) { b.nb = (b.nb + 7u) & ~7u; lz_bv_flush(b); }     // next bits start on a byte boundary
+LZ_DEV u32  lz_bv_bytes(const LzBitV& b) { return 4u * b.words + (b.nb >> 3); }    // after lz_bv_align
+
+// HUF_setMaxHeight, huf_compress.c:223-297, on the sorted leaves 0..lastNonNull: bits = code length by rank, leaf = count << 8 | symbol.
+LZ_DEV u32 lz_huf_set_max_height(const LzV256& leaf, LzV256& bits, u32 lastNonNull, u32 maxNbBits)
+{
+    const u32 largestBits = bits.get(lastNonNull);
     if (largestBits <= maxNbBits) return largestBits;
     const u32 noSymbol = 0xF0F0F0F0u;
     int totalCost = 0;
     const u32 baseCost = 1u << (largestBits - maxNbBits);
     int n = (int)lastNonNull;
-    u32 rankLast[LZ_HUF_MAXBITS + 2];
-    while (nbits[n] > maxNbBits) {
-        totalCost += (int)(baseCost - (1u << (largestBits - nbits[n])));
-        nbits[n] = (u8)maxNbBits;
+    LzV64 rankLast; rankLast.r = noSymbol;                       // [LZ_HUF_MAXBITS + 2]
+    while (bits.get((u32)n) > maxNbBits) {
+        totalCost += (int)(baseCost - (1u << (largestBits - bits.get((u32)n))));
+        bits.set((u32)n, maxNbBits);
         n--;
     }
-    while (n >= 0 && nbits[n] == maxNbBits) n--;          // the reference stops on the barrier node (nbBits 0)
+    while (n >= 0 && bits.get((u32)n) == maxNbBits) n--;        // the reference stops on the barrier node (nbBits 0)
     totalCost >>= (largestBits - maxNbBits);
-    for (u32 i = 0; i < LZ_HUF_MAXBITS + 2; i++) rankLast[i] = noSymbol;
     {
         u32 cur = maxNbBits;
         for (int pos = n; pos >= 0; pos--) {
-            if (nbits[pos] >= cur) continue;
-            cur = nbits[pos];
-            rankLast[maxNbBits - cur] = (u32)pos;
+            const u32 nb = bits.get((u32)pos);
+            if (nb >= cur) continue;
+            cur = nb;
+            rankLast.set(maxNbBits - cur, (u32)pos);
         }
     }
     while (totalCost > 0) {
         u32 dec = lz_highbit((u32)totalCost) + 1u;
         for (; dec > 1u; dec--) {
-            const u32 highPos = rankLast[dec], lowPos = rankLast[dec - 1u];
+            const u32 highPos = rankLast.get(dec), lowPos = rankLast.get(dec - 1u);
             if (highPos == noSymbol) continue;
             if (lowPos == noSymbol) break;
-            if (nodeCnt[highPos] <= 2u * nodeCnt[lowPos]) break;
+            if ((leaf.get(highPos) >> 8) <= 2u * (leaf.get(lowPos) >> 8)) break;
         }
-        while (dec <= LZ_HUF_MAXBITS && rankLast[dec] == noSymbol) dec++;
+        while (dec <= LZ_HUF_MAXBITS && rankLast.get(dec) == noSymbol) dec++;
         totalCost -= 1 << (dec - 1u);
-        if (rankLast[dec - 1u] == noSymbol) rankLast[dec - 1u] = rankLast[dec];
-        nbits[rankLast[dec]]++;
-        if (rankLast[dec] == 0) rankLast[dec] = noSymbol;
-        else {
-            rankLast[dec]--;
-            if (nbits[rankLast[dec]] != maxNbBits - dec) rankLast[dec] = noSymbol;
+        if (rankLast.get(dec - 1u) == noSymbol) rankLast.set(dec - 1u, rankLast.get(dec));
+        {
+            const u32 rl = rankLast.get(dec);
+            bits.set(rl, bits.get(rl) + 1u);
+            if (rl == 0) rankLast.set(dec, noSymbol);
+            else {
+                rankLast.set(dec, rl - 1u);
+                if (bits.get(rl - 1u) != maxNbBits - dec) rankLast.set(dec, noSymbol);
+            }
         }
     }
     while (totalCost < 0) {
-        if (rankLast[1] == noSymbol) {
-            while (nbits[n] == maxNbBits) n--;
-            nbits[n + 1]--;
-            rankLast[1] = (u32)(n + 1);
+        if (rankLast.get(1) == noSymbol) {
+            while (bits.get((u32)n) == maxNbBits) n--;
+            bits.set((u32)(n + 1), bits.get((u32)(n + 1)) - 1u);
+            rankLast.set(1, (u32)(n + 1));
             totalCost++;
             continue;
         }
-        nbits[rankLast[1] + 1u]--;
-        rankLast[1]++;
+        {
+            const u32 rl = rankLast.get(1) + 1u;
+            bits.set(rl, bits.get(rl) - 1u);
+            rankLast.set(1, rl);
+        }
         totalCost++;
     }
     return maxNbBits;
 }
 
-// FSE_normalizeCount + FSE_normalizeM2, fse_compress.c:507-641 (lane 0). Returns false on the
-// reference's error returns.
-LZ_DEV bool lz_fse_normalize(short* norm, u32 tableLog, const u32* count, u32 total, u32 maxSym)
+// FSE_normalizeCount + FSE_normalizeM2, fse_compress.c:507-641.  count / norm: tables of <= 13 entries (norm holds
+// signed values).  Returns false on the reference's error returns.
+LZ_DEV bool lz_fse_normalize(LzV64& norm, u32 tableLog, const LzV64& count, u32 total, u32 maxSym)
 {
-    const u32 rtb[8] = { 0, 473195, 504333, 520860, 550000, 700000, 750000, 830000 };
     const u64 scale = 62u - tableLog, step = ((u64)1 << 62) / total, vStep = 1ULL << (scale - 20u);
     int still = 1 << tableLog;
     u32 largest = 0;
-    short largestP = 0;
+    int largestP = 0;
     const u32 lowThreshold = total >> tableLog;
     {
         const u32 minBitsSrc = lz_highbit(total - 1u) + 1u, minBitsSym = lz_highbit(maxSym) + 2u;
         if (tableLog < (minBitsSrc < minBitsSym ? minBitsSrc : minBitsSym)) return false;
     }
     for (u32 s = 0; s <= maxSym; s++) {
-        if (count[s] == 0) { norm[s] = 0; continue; }
-        if (count[s] <= lowThreshold) { norm[s] = -1; still--; }
+        const u32 c = count.get(s);
+        if (c == 0) { norm.set(s, 0); continue; }
+        if (c <= lowThreshold) { norm.set(s, (u32)-1); still--; }
         else {
-            short proba = (short)((count[s] * step) >> scale);
-            if (proba < 8) {
-                u32 r = 0;                                    // rtb[proba] without a dynamically indexed private array
-                for (int k = 0; k < 8; k++) if (k == proba) r = rtb[k];
+            int proba = (int)(short)((c * step) >> scale);
+            if (proba < 8) {                                  // rtbTable, fse_compress.c:592
+                const u32 r = proba == 1 ? 473195u : proba == 2 ? 504333u : proba == 3 ? 520860u : proba == 4 ? 550000u
+                            : proba == 5 ? 700000u : proba == 6 ? 750000u : proba == 7 ? 830000u : 0u;
                 const u64 restToBeat = vStep * r;
-                proba += (count[s] * step) - ((u64)proba << scale) > restToBeat;
+                proba += (c * step) - ((u64)proba << scale) > restToBeat;
             }
             if (proba > largestP) { largestP = proba; largest = s; }
-            norm[s] = proba;
+            norm.set(s, (u32)proba);
             still -= proba;
         }
     }
-    if (-still < (norm[largest] >> 1)) { norm[largest] += (short)still; return true; }
+    if (-still < ((int)norm.get(largest) >> 1)) { norm.set(largest, (u32)((int)norm.get(largest) + still)); return true; }
     // FSE_normalizeM2
     {
         u32 distributed = 0, toDistribute;
         u64 tot = total;
         u32 lowOne = (u32)((tot * 3u) >> (tableLog + 1u));
         for (u32 s = 0; s <= maxSym; s++) {
-            if (count[s] == 0) { norm[s] = 0; continue; }
-            if (count[s] <= lowThreshold) { norm[s] = -1; distributed++; tot -= count[s]; continue; }
-            if (count[s] <= lowOne) { norm[s] = 1; distributed++; tot -= count[s]; continue; }
-            norm[s] = -2;
+            const u32 c = count.get(s);
+            if (c == 0) { norm.set(s, 0); continue; }
+            if (c <= lowThreshold) { norm.set(s, (u32)-1); distributed++; tot -= c; continue; }
+            if (c <= lowOne) { norm.set(s, 1); distributed++; tot -= c; continue; }
+            norm.set(s, (u32)-2);
         }
         toDistribute = (1u << tableLog) - distributed;
         if ((tot / toDistribute) > lowOne) {
             lowOne = (u32)((tot * 3u) / (toDistribute * 2u));
-            for (u32 s = 0; s <= maxSym; s++)
-                if (norm[s] == -2 && count[s] <= lowOne) { norm[s] = 1; distributed++; tot -= count[s]; }
+            for (u32 s = 0; s <= maxSym; s++) {
+                const u32 c = count.get(s);
+                if ((int)norm.get(s) == -2 && c <= lowOne) { norm.set(s, 1); distributed++; tot -= c; }
+            }
             toDistribute = (1u << tableLog) - distributed;
         }
         if (distributed == maxSym + 1u) {
             u32 maxV = 0, maxC = 0;
-            for (u32 s = 0; s <= maxSym; s++) if (count[s] > maxC) { maxV = s; maxC = count[s]; }
-            norm[maxV] += (short)toDistribute;
+            for (u32 s = 0; s <= maxSym; s++) { const u32 c = count.get(s); if (c > maxC) { maxV = s; maxC = c; } }
+            norm.set(maxV, (u32)((int)norm.get(maxV) + (int)toDistribute));
             return true;
         }
         const u64 vStepLog = 62u - tableLog, mid = (1ULL << (vStepLog - 1u)) - 1u;
         const u64 rStep = ((((u64)1 << vStepLog) * toDistribute) + mid) / tot;
         u64 tmpTotal = mid;
-        for (u32 s = 0; s <= maxSym; s++) if (norm[s] == -2) {
-            const u64 end = tmpTotal + (count[s] * rStep);
+        for (u32 s = 0; s <= maxSym; s++) if ((int)norm.get(s) == -2) {
+            const u64 end = tmpTotal + (count.get(s) * rStep);
             const u32 weight = (u32)(end >> vStepLog) - (u32)(tmpTotal >> vStepLog);
             if (weight < 1u) return false;
-            norm[s] = (short)weight;
+            norm.set(s, weight);
             tmpTotal = end;
         }
     }
     return true;
 }
 
-// HUF_compressWeights, huf_compress.c:81-121 (lane 0): FSE-compress wt[0..wtSize) to dst.
-// Returns compressed size, 0 = not compressible, 1 = all equal, 0xFFFFFFFF = reference error.
-// `fse` = 160 words of LDS scratch, wt lives in LDS too.
-LZ_DEV u32 lz_huf_compress_weights(u8* dst, const u8* wt, u32 wtSize, u32* fse)
+// HUF_compressWeights, huf_compress.c:81-121: FSE-compress the weights of symbols 0..wtSize-1 into the register table
+// b.out (byte stream, LSB first).  wt4: lane l holds the weights of symbols 4l..4l+3, one per byte.  count[w]: number of
+// symbols with weight w.  Returns the compressed size, 0 = not compressible, 1 = all equal, 0xFFFFFFFF = reference error.
+LZ_DEV u32 lz_huf_compress_weights(LzBitV& b, u32 wt4, u32 wtSize, const LzV64& count)
 {
-    u32*  count      = fse;                  // [13]
-    short* norm      = (short*)(fse + 16);   // [13]
-    u32*  cumul      = fse + 24;             // [15]
-    u32*  dBits      = fse + 40;             // [13]
-    int*  dFind      = (int*)(fse + 56);     // [13]
-    u16*  stateTable = (u16*)(fse + 72);     // [64]
-    u8*   tableSym   = (u8*)(fse + 104);     // [64]
+#define LZ_WT(i) ((lz_readlane(wt4, (i) >> 2) >> (8u * ((i) & 3u))) & 255u)
+    lz_bv_init(b);
     if (wtSize <= 1u) return 0;
-    for (u32 s = 0; s <= LZ_HUF_MAXBITS; s++) count[s] = 0;
-    for (u32 s = 0; s < wtSize; s++) count[wt[s]]++;
     u32 maxSym = LZ_HUF_MAXBITS, maxCount = 0;
-    while (!count[maxSym]) maxSym--;
-    for (u32 s = 0; s <= maxSym; s++) if (count[s] > maxCount) maxCount = count[s];
+    while (!count.get(maxSym)) maxSym--;
+    for (u32 s = 0; s <= maxSym; s++) { const u32 c = count.get(s); if (c > maxCount) maxCount = c; }
     if (maxCount == wtSize) return 1;
     if (maxCount == 1u) return 0;
     const u32 tableLog = lz_fse_optimal_tablelog(6u, wtSize, maxSym, 2u);
+    LzV64 norm; norm.r = 0;
     if (!lz_fse_normalize(norm, tableLog, count, wtSize, maxSym)) return 0xFFFFFFFFu;
-    u32 pos;
     {   // FSE_writeNCount_generic, fse_compress.c:204-289
-        LzBitW b; b.p = dst; b.pos = 0; b.acc = 0; b.nb = 0;
         int nbBits = (int)tableLog + 1, remaining = (1 << tableLog) + 1, threshold = 1 << tableLog;
         u32 charnum = 0;
         bool previous0 = false;
-        lz_bw_add(b, tableLog - 5u, 4u);
+        lz_bv_add(b, tableLog - 5u, 4u);
         while (remaining > 1) {
             if (previous0) {
                 u32 start = charnum;
-                while (!norm[charnum]) charnum++;
-                while (charnum >= start + 24u) { start += 24u; lz_bw_add(b, 0xFFFFu, 16u); }
-                while (charnum >= start + 3u) { start += 3u; lz_bw_add(b, 3u, 2u); }
-                lz_bw_add(b, charnum - start, 2u);
+                while (!norm.get(charnum)) charnum++;
+                while (charnum >= start + 24u) { start += 24u; lz_bv_add(b, 0xFFFFu, 16u); }
+                while (charnum >= start + 3u) { start += 3u; lz_bv_add(b, 3u, 2u); }
+                lz_bv_add(b, charnum - start, 2u);
             }
-            int cnt = norm[charnum++];
+            int cnt = (int)norm.get(charnum++);
             const int mx = (2 * threshold - 1) - remaining;
             remaining -= cnt < 0 ? -cnt : cnt;
             cnt++;
             if (cnt >= threshold) cnt += mx;
-            lz_bw_add(b, (u32)cnt, (u32)(nbBits - (cnt < mx)));
+            lz_bv_add(b, (u32)cnt, (u32)(nbBits - (cnt < mx)));
             previous0 = (cnt == 1);
             if (remaining < 1) return 0xFFFFFFFFu;
             while (remaining < threshold) { nbBits--; threshold >>= 1; }
         }
         if (charnum > maxSym + 1u) return 0xFFFFFFFFu;
-        pos = lz_bw_finish(b);
+        lz_bv_align(b);
     }
-    {   // FSE_buildCTable_wksp, fse_compress.c:103-182
+    // FSE_buildCTable_wksp, fse_compress.c:103-182: all tables have at most 64 entries
+    LzV64 cumul, tableSym, stateTable, dBits, dFind;
+    cumul.r = tableSym.r = stateTable.r = dBits.r = dFind.r = 0;
+    {
         const u32 tableSize = 1u << tableLog, mask = tableSize - 1u, step = (tableSize >> 1) + (tableSize >> 3) + 3u;
         u32 high = tableSize - 1u, position = 0, total = 0;
-        cumul[0] = 0;
+        cumul.set(0, 0);
         for (u32 u = 1; u <= maxSym + 1u; u++) {
-            if (norm[u - 1u] == -1) { cumul[u] = cumul[u - 1u] + 1u; tableSym[high--] = (u8)(u - 1u); }
-            else cumul[u] = cumul[u - 1u] + (u32)norm[u - 1u];
+            const int nv = (int)norm.get(u - 1u);
+            if (nv == -1) { cumul.set(u, cumul.get(u - 1u) + 1u); tableSym.set(high--, u - 1u); }
+            else cumul.set(u, cumul.get(u - 1u) + (u32)nv);
         }
-        for (u32 s = 0; s <= maxSym; s++)
-            for (int k = 0; k < norm[s]; k++) {
-                tableSym[position] = (u8)s;
+        for (u32 s = 0; s <= maxSym; s++) {
+            const int nv = (int)norm.get(s);
+            for (int k = 0; k < nv; k++) {
+                tableSym.set(position, s);
                 position = (position + step) & mask;
                 while (position > high) position = (position + step) & mask;
             }
+        }
         if (position != 0) return 0xFFFFFFFFu;
-        for (u32 u = 0; u < tableSize; u++) { const u32 sy = tableSym[u]; stateTable[cumul[sy]++] = (u16)(tableSize + u); }
+        for (u32 u = 0; u < tableSize; u++) { const u32 sy = tableSym.get(u); const u32 cu = cumul.get(sy); stateTable.set(cu, tableSize + u); cumul.set(sy, cu + 1u); }
         for (u32 s = 0; s <= maxSym; s++) {
-            if (norm[s] == 0) { dBits[s] = 0; dFind[s] = 0; }
-            else if (norm[s] == -1 || norm[s] == 1) { dBits[s] = (tableLog << 16) - (1u << tableLog); dFind[s] = (int)total - 1; total++; }
+            const int nv = (int)norm.get(s);
+            if (nv == 0) { dBits.set(s, 0); dFind.set(s, 0); }
+            else if (nv == -1 || nv == 1) { dBits.set(s, (tableLog << 16) - (1u << tableLog)); dFind.set(s, total - 1u); total++; }
             else {
-                const u32 maxBitsOut = tableLog - lz_highbit((u32)norm[s] - 1u);
-                const u32 minStatePlus = (u32)norm[s] << maxBitsOut;
-                dBits[s] = (maxBitsOut << 16) - minStatePlus; dFind[s] = (int)total - norm[s]; total += (u32)norm[s];
+                const u32 maxBitsOut = tableLog - lz_highbit((u32)nv - 1u);
+                const u32 minStatePlus = (u32)nv << maxBitsOut;
+                dBits.set(s, (maxBitsOut << 16) - minStatePlus); dFind.set(s, total - (u32)nv); total += (u32)nv;
             }
         }
     }
     // FSE_compress_usingCTable_generic, fse_compress.c:701-758 (+ fse.h:525-564): two interleaved states
     if (wtSize <= 2u) return 0;
-    LzBitW b; b.p = dst + pos; b.pos = 0; b.acc = 0; b.nb = 0;
+    const u32 pos = lz_bv_bytes(b);
     long long st1, st2;
     u32 i = wtSize;
-#define LZ_FSE_INIT2(S, sym) do { const u32 nbo_ = (dBits[sym] + (1u << 15)) >> 16; const long long v_ = ((long long)nbo_ << 16) - dBits[sym]; \
-                                  (S) = stateTable[(v_ >> nbo_) + dFind[sym]]; } while (0)
-#define LZ_FSE_ENC(S, sym) do { const u32 nbo_ = (u32)(((S) + dBits[sym]) >> 16); lz_bw_add(b, (u32)(S), nbo_); \
-                                (S) = stateTable[((S) >> nbo_) + dFind[sym]]; } while (0)
-    if (wtSize & 1u) { LZ_FSE_INIT2(st1, wt[i - 1u]); LZ_FSE_INIT2(st2, wt[i - 2u]); i -= 3u; LZ_FSE_ENC(st1, wt[i]); }
-    else             { LZ_FSE_INIT2(st2, wt[i - 1u]); LZ_FSE_INIT2(st1, wt[i - 2u]); i -= 2u; }
+#define LZ_FSE_INIT2(S, sym) do { const u32 sy_ = (sym); const u32 db_ = dBits.get(sy_); const u32 nbo_ = (db_ + (1u << 15)) >> 16; \
+                                  const long long v_ = ((long long)nbo_ << 16) - db_; \
+                                  (S) = stateTable.get((u32)((v_ >> nbo_) + (int)dFind.get(sy_))); } while (0)
+#define LZ_FSE_ENC(S, sym) do { const u32 sy_ = (sym); const u32 nbo_ = (u32)(((S) + dBits.get(sy_)) >> 16); lz_bv_add(b, (u32)(S), nbo_); \
+                                (S) = stateTable.get((u32)(((S) >> nbo_) + (int)dFind.get(sy_))); } while (0)
+    if (wtSize & 1u) { LZ_FSE_INIT2(st1, LZ_WT(i - 1u)); LZ_FSE_INIT2(st2, LZ_WT(i - 2u)); i -= 3u; LZ_FSE_ENC(st1, LZ_WT(i)); }
+    else             { LZ_FSE_INIT2(st2, LZ_WT(i - 1u)); LZ_FSE_INIT2(st1, LZ_WT(i - 2u)); i -= 2u; }
     bool useSt2 = true;
-    while (i > 0) { i--; if (useSt2) LZ_FSE_ENC(st2, wt[i]); else LZ_FSE_ENC(st1, wt[i]); useSt2 = !useSt2; }
-    lz_bw_add(b, (u32)st2, tableLog);
-    lz_bw_add(b, (u32)st1, tableLog);
-    lz_bw_add(b, 1u, 1u);                                     // BIT_closeCStream end mark
+    while (i > 0) { i--; if (useSt2) LZ_FSE_ENC(st2, LZ_WT(i)); else LZ_FSE_ENC(st1, LZ_WT(i)); useSt2 = !useSt2; }
+    lz_bv_add(b, (u32)st2, tableLog);
+    lz_bv_add(b, (u32)st1, tableLog);
+    lz_bv_add(b, 1u, 1u);                                     // BIT_closeCStream end mark
+    lz_bv_align(b);
+    b.out.set(b.words & 63u, (u32)b.acc);                     // the last, partial dword
 #undef LZ_FSE_INIT2
 #undef LZ_FSE_ENC
-    return pos + lz_bw_finish(b);
+#undef LZ_WT
+    (void)pos;
+    return lz_bv_bytes(b);
 }
 
 // One 1X bitstream (huf_compress.c:427-470): symbols src[a..b) appended LAST -> FIRST, LSB first, then a
@@ -375,11 +415,6 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
     }
     u32* count = ws + LZ_HUF_WS_COUNT;
     u16* ctab = (u16*)(ws + LZ_HUF_WS_CTAB);
-    u32* nodeCnt = ws + LZ_HUF_WS_NODECNT + 1;                 // nodeCnt[-1] = barrier
-    u16* parent = (u16*)(ws + LZ_HUF_WS_PARENT);
-    u8* nbyte = (u8*)(ws + LZ_HUF_WS_BYTE);
-    u8* nbits = (u8*)(ws + LZ_HUF_WS_NBITS);
-    u32* fse = ws + LZ_HUF_WS_FSE;
     u8* payload = op + 6;
 
     LZ_HPROF(14);
@@ -398,7 +433,7 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
         for (u32 i = n4 + lane; i < n; i += 64u) lz_lds_atomic_add(&count[stream[i]], 1u);
     }
     lz_lds_sync();
-    u32 c4[4];
+    u32 c4[4];                                                 // my four symbols: 4*lane .. 4*lane+3
     for (u32 k = 0; k < 4u; k++) c4[k] = count[lane * 4u + k];
     u32 myMax = c4[0], myTop = 0; bool any = c4[0] != 0;
     for (u32 k = 1; k < 4u; k++) { if (c4[k] > myMax) myMax = c4[k]; if (c4[k]) { myTop = k; any = true; } }
@@ -415,7 +450,7 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
         lz_converge();
         csize = 1; accept = true;
     } else if (largest > (n >> 7) + 1u) {                      // :545 otherwise "not compressible"
-        // ---- sort: node[rank] = (count, symbol), descending count, ties ascending symbol (:305-325) ----
+        // ---- sort: leaf[rank] = (count, symbol), descending count, ties ascending symbol (:305-325) ----
         u32 rank[4] = { 0, 0, 0, 0 };
         for (u32 t = 0; t <= maxSym; t++) {
             const u32 ct = count[t];
@@ -424,70 +459,146 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
                 rank[k] += (ct > c4[k] || (ct == c4[k] && t < s)) ? 1u : 0u;
             }
         }
-        lz_lds_sync();
-        for (u32 i = lane; i < 514u; i += 64u) ws[LZ_HUF_WS_NODECNT + i] = 0;
-        for (u32 i = lane; i < 256u; i += 64u) ((u32*)parent)[i] = 0;
-        for (u32 i = lane; i < 128u; i += 64u) { if (i < 64u) ((u32*)nbyte)[i] = 0; ((u32*)nbits)[i] = 0; }
-        lz_lds_sync();
+        const u32 nonNull = lz_popc64(lz_ballot(c4[0] != 0)) + lz_popc64(lz_ballot(c4[1] != 0))
+                          + lz_popc64(lz_ballot(c4[2] != 0)) + lz_popc64(lz_ballot(c4[3] != 0)) - 1u;   // last rank with a count (>= 1 here)
+        lz_lds_sync();                                         // every lane has read the counts
         for (u32 k = 0; k < 4u; k++) {
             const u32 s = lane * 4u + k;
-            if (s <= maxSym) { nodeCnt[rank[k]] = c4[k]; nbyte[rank[k]] = (u8)s; }
+            if (s <= maxSym) count[rank[k]] = (c4[k] << 8) | s;      // ranks of the symbols 0..maxSym are a permutation of 0..maxSym
         }
         lz_lds_sync();
+        LzV256 leaf;                                           // by rank: count << 8 | symbol (0 past maxSym)
+        leaf.r0 = lane <= maxSym ? count[lane] : 0u;
+        leaf.r1 = 64u + lane <= maxSym ? count[64u + lane] : 0u;
+        leaf.r2 = 128u + lane <= maxSym ? count[128u + lane] : 0u;
+        leaf.r3 = 192u + lane <= maxSym ? count[192u + lane] : 0u;
         LZ_HPROF(9);                                           // rank sort
-        // ---- lane 0: tree, depth limit, canonical codes, weight header ----
-        u32 hdr = 0;                                           // header size, 0 = reference error -> raw (lane 0's value,
-                                                               // broadcast through LDS: fse[159])
-        u32 huffLog = lz_fse_optimal_tablelog(LZ_HUF_DEFAULTLOG, n, maxSym, 1u);   // HUF_optimalTableLog :66
-        if (lane == 0) {
-            const u32 START = 256u;                            // STARTNODE, :333
-            u32 nonNull = maxSym;
-            while (nodeCnt[nonNull] == 0) nonNull--;
-            int lowS = (int)nonNull, lowN = (int)START;
-            u32 nodeNb = START;
-            const u32 nodeRoot = nodeNb + (u32)lowS - 1u;
-            nodeCnt[nodeNb] = nodeCnt[lowS] + nodeCnt[lowS - 1];
-            parent[lowS] = parent[lowS - 1] = (u16)nodeNb;
-            nodeNb++; lowS -= 2;
-            for (u32 i = nodeNb; i <= nodeRoot; i++) nodeCnt[i] = 1u << 30;
-            nodeCnt[-1] = 1u << 31;                            // barrier, :351
-            while (nodeNb <= nodeRoot) {                       // :353-369 (ties -> internal node)
-                const int n1 = (nodeCnt[lowS] < nodeCnt[lowN]) ? lowS-- : lowN++;
-                const int n2 = (nodeCnt[lowS] < nodeCnt[lowN]) ? lowS-- : lowN++;
-                nodeCnt[nodeNb] = nodeCnt[n1] + nodeCnt[n2];
-                parent[n1] = parent[n2] = (u16)nodeNb;
+        // ---- tree (huf_compress.c:334-376): the two-queue merge, heads of both queues kept in scalars ----
+        // internal node k stands for the reference's huffNode[256 + k]; parL / parN: parent (as k) of leaf rank i / of node k
+        LzV256 nodeC, parL, parN;
+        nodeC.r0 = nodeC.r1 = nodeC.r2 = nodeC.r3 = 0; parL = nodeC; parN = nodeC;
+        const u32 kRoot = nonNull - 1u;
+        {
+            const u32 BAR = 1u << 31, BIG = 1u << 30;          // :351 barrier below the leaves, :350 nodes not made yet
+            int lowS = (int)nonNull;
+            u32 lowN = 0, nodeNb = 0;
+            {   // :344-347
+                const u32 c = (leaf.get((u32)lowS) >> 8) + (leaf.get((u32)lowS - 1u) >> 8);
+                nodeC.set(0, c); parL.set((u32)lowS, 0); parL.set((u32)lowS - 1u, 0);
+                nodeNb = 1; lowS -= 2;
+            }
+            u32 curS = lowS >= 0 ? leaf.get((u32)lowS) >> 8 : BAR;
+            u32 curN = nodeC.get(0);
+            while (nodeNb <= kRoot) {                          // :353-369 (a leaf is taken only when strictly smaller)
+                u32 sum = 0;
+                for (u32 pick = 0; pick < 2u; pick++) {
+                    if (curS < curN) { sum += curS; parL.set((u32)lowS, nodeNb); lowS--; curS = lowS >= 0 ? leaf.get((u32)lowS) >> 8 : BAR; }
+                    else             { sum += curN; parN.set(lowN, nodeNb); lowN++; curN = lowN < nodeNb ? nodeC.get(lowN) : BIG; }
+                }
+                nodeC.set(nodeNb, sum);
+                if (lowN == nodeNb) curN = sum;                // the new node is the head of the node queue
                 nodeNb++;
             }
-            nbits[nodeRoot] = 0;                               // :371-376
-            for (u32 i = nodeRoot - 1u; i >= START; i--) nbits[i] = (u8)(nbits[parent[i]] + 1u);
-            for (u32 i = 0; i <= nonNull; i++) nbits[i] = (u8)(nbits[parent[i]] + 1u);
-            huffLog = lz_huf_set_max_height(nodeCnt, nbits, nonNull, huffLog);   // :379
-            // canonical values (:381-398) -> ctab[symbol] = val | nbBits << 12  (val < 2^nbBits <= 2^12)
-            u32 nbPerRank[LZ_HUF_MAXBITS + 1], valPerRank[LZ_HUF_MAXBITS + 1];
-            for (u32 i = 0; i <= LZ_HUF_MAXBITS; i++) { nbPerRank[i] = 0; valPerRank[i] = 0; }
-            for (u32 i = 0; i <= nonNull; i++) nbPerRank[nbits[i]]++;
-            { u32 mn = 0; for (u32 i = huffLog; i > 0; i--) { valPerRank[i] = mn; mn = (mn + nbPerRank[i]) & 0xFFFFu; mn >>= 1; } }
-            for (u32 i = 0; i < 256u; i++) ctab[i] = 0;
-            for (u32 i = 0; i <= maxSym; i++) ctab[nbyte[i]] = (u16)((u32)nbits[i] << 12);
-            for (u32 s = 0; s <= maxSym; s++) { const u32 nb = ctab[s] >> 12; ctab[s] = (u16)(ctab[s] | ((valPerRank[nb]++) & 0xFFFu)); }
-            // HUF_writeCTable (:132-165): weights of symbols 0..maxSym-1 into count[] (free now), as bytes
-            u8* wt = (u8*)count;
-            for (u32 s = 0; s < maxSym; s++) { const u32 nb = ctab[s] >> 12; wt[s] = nb ? (u8)(huffLog + 1u - nb) : 0; }
-            const u32 h = lz_huf_compress_weights(payload + 1, wt, maxSym, fse);
+        }
+        // depths (:371-376).  Node depths by pointer jumping in LDS: word k = distance << 8 | ancestor, the root points at itself;
+        // after r rounds every node has jumped 2^r levels, eight rounds cover any tree of 256 leaves.  Then the leaves.
+        lz_lds_sync();
+        {
+            u32 w[4];
+            w[0] = parN.r0; w[1] = parN.r1; w[2] = parN.r2; w[3] = parN.r3;
+            for (u32 j = 0; j < 4u; j++) {
+                const u32 k = 64u * j + lane;
+                w[j] = k < kRoot ? (1u << 8) | w[j] : kRoot;     // (entries past the root are never looked at)
+                count[k] = w[j];
+            }
+            lz_lds_sync();
+            for (u32 round = 0; round < 8u; round++) {
+                u32 nw[4];
+                for (u32 j = 0; j < 4u; j++) { const u32 up = count[w[j] & 255u]; nw[j] = ((w[j] >> 8) + (up >> 8)) << 8 | (up & 255u); }
+                lz_lds_sync();
+                for (u32 j = 0; j < 4u; j++) { w[j] = nw[j]; count[64u * j + lane] = w[j]; }
+                lz_lds_sync();
+            }
+        }
+        LzV256 bits;                                           // by rank: code length (0 past nonNull)
+        bits.r0 = lane <= nonNull ? (count[parL.r0] >> 8) + 1u : 0u;
+        bits.r1 = 64u + lane <= nonNull ? (count[parL.r1] >> 8) + 1u : 0u;
+        bits.r2 = 128u + lane <= nonNull ? (count[parL.r2] >> 8) + 1u : 0u;
+        bits.r3 = 192u + lane <= nonNull ? (count[parL.r3] >> 8) + 1u : 0u;
+        u32 huffLog = lz_fse_optimal_tablelog(LZ_HUF_DEFAULTLOG, n, maxSym, 1u);   // HUF_optimalTableLog :66
+        huffLog = lz_huf_set_max_height(leaf, bits, nonNull, huffLog);            // :379
+        // ---- code length per symbol: through LDS by rank ----
+        lz_lds_sync();
+        count[lane] = bits.r0; count[64u + lane] = bits.r1; count[128u + lane] = bits.r2; count[192u + lane] = bits.r3;
+        lz_lds_sync();
+        u32 nb4[4];
+        for (u32 k = 0; k < 4u; k++) nb4[k] = (lane * 4u + k <= maxSym && c4[k] != 0) ? count[rank[k]] : 0u;
+        // ---- canonical values (:381-398): symbols of one length are numbered in symbol order, the longest codes get the
+        // smallest values.  Counting "symbols before me with my length" = exclusive prefix sums of 12 counters, packed three
+        // to a dword (10 bits each; there are at most 256 symbols): four wave scans instead of a pass per symbol. ----
+        u32 pk[4] = { 0, 0, 0, 0 };
+        for (u32 k = 0; k < 4u; k++) if (nb4[k]) { const u32 b_ = nb4[k] - 1u; pk[b_ / 3u] += 1u << (10u * (b_ % 3u)); }
+        u32 pre[4], tot[4];
+        for (u32 j = 0; j < 4u; j++) { const u32 inc = lz_wave_scan_excl_add(pk[j]); pre[j] = inc; tot[j] = lz_readlane(inc + pk[j], 63u); }
+        LzV64 valPerRank; valPerRank.r = 0;
+        LzV64 wcount; wcount.r = 0;                             // weight histogram of the symbols 0..maxSym-1 (HUF_compressWeights)
+        {
+            u32 mn = 0;
+            for (u32 i = huffLog; i > 0; i--) {                // :388-393
+                const u32 b_ = i - 1u;
+                const u32 cnt = (tot[b_ / 3u] >> (10u * (b_ % 3u))) & 1023u;     // nbPerRank[i]
+                valPerRank.set(i, mn);
+                mn = (mn + cnt) >> 1;
+                wcount.set(huffLog + 1u - i, cnt);
+            }
+        }
+        u32 wt4 = 0;                                           // my four weights, one per byte (symbol maxSym itself has none)
+        {
+            u32 seen[4] = { 0, 0, 0, 0 };                      // my own earlier symbols, same packing
+            for (u32 k = 0; k < 4u; k++) {
+                const u32 s = lane * 4u + k, nb = nb4[k];
+                const u32 first = lz_shfl(valPerRank.r, nb);   // valPerRank[nb]; outside any branch: a cross-lane read needs its source lane active
+                u32 code = 0;
+                if (nb) {
+                    const u32 b_ = nb - 1u, sh = 10u * (b_ % 3u);
+                    const u32 before = ((pre[b_ / 3u] + seen[b_ / 3u]) >> sh) & 1023u;
+                    code = ((first + before) & 0xFFFu) | (nb << 12);
+                    seen[b_ / 3u] += 1u << sh;
+                    if (s < maxSym) wt4 |= (huffLog + 1u - nb) << (8u * k);
+                }
+                ctab[s] = (u16)code;
+            }
+        }
+        // ---- HUF_writeCTable (:132-165): weights of symbols 0..maxSym-1, FSE-compressed or as nibbles ----
+        u32 hdr = 0;                                           // header size, 0 = reference error -> raw
+        {
+            // the symbol maxSym is in wcount but has no weight in the header: take it out; weight 0 = absent symbols below maxSym
+            const u32 nbLast = (lz_readlane(nb4[0] | (nb4[1] << 8) | (nb4[2] << 16) | (nb4[3] << 24), maxSym >> 2) >> (8u * (maxSym & 3u))) & 255u;
+            const u32 wLast = huffLog + 1u - nbLast;
+            wcount.set(wLast, wcount.get(wLast) - 1u);
+            wcount.set(0, maxSym - nonNull);
+            LzBitV b;
+            const u32 h = lz_huf_compress_weights(b, wt4, maxSym, wcount);
             if (h == 0xFFFFFFFFu) hdr = 0;
-            else if (h > 1u && h < maxSym / 2u) { payload[0] = (u8)h; hdr = h + 1u; }
+            else if (h > 1u && h < maxSym / 2u) {
+                if (lane == 0) payload[0] = (u8)h;
+                lz_converge();
+                for (u32 k = 0; k < 4u; k++) if (4u * lane + k < h) payload[1u + 4u * lane + k] = (u8)(b.out.r >> (8u * k));
+                hdr = h + 1u;
+            }
             else if (maxSym > 128u) hdr = 0;                   // :158 ERROR(GENERIC)
             else {
-                payload[0] = (u8)(128u + (maxSym - 1u));
-                wt[maxSym] = 0;
-                for (u32 s = 0; s < maxSym; s += 2u) payload[s / 2u + 1u] = (u8)((wt[s] << 4) + wt[s + 1u]);
-                hdr = (maxSym + 1u) / 2u + 1u;
+                if (lane == 0) payload[0] = (u8)(128u + (maxSym - 1u));
+                lz_converge();
+                // two weights per byte: symbols 2i, 2i+1 -> my four symbols give bytes 2*lane and 2*lane+1 (weights past maxSym-1 are 0)
+                const u32 nBytes = (maxSym + 1u) / 2u;
+                if (2u * lane < nBytes) payload[1u + 2u * lane] = (u8)(((wt4 & 15u) << 4) | ((wt4 >> 8) & 15u));
+                if (2u * lane + 1u < nBytes) payload[2u + 2u * lane] = (u8)((((wt4 >> 16) & 15u) << 4) | ((wt4 >> 24) & 15u));
+                hdr = nBytes + 1u;
             }
-            fse[159] = hdr;
         }
-        lz_lds_sync();
-        hdr = lz_uniform(fse[159]);
-        LZ_HPROF(10);                                          // lane-0 tree / codes / header
+        lz_lds_sync();                                         // ctab visible to every lane
+        LZ_HPROF(10);                                          // tree / codes / header
         if (hdr != 0 && hdr + 12u < n) {                       // :556
             // ---- exact stream sizes: sum of code lengths per segment (huf_compress.c:473-513) ----
             const u32 seg = (n + 3u) / 4u;

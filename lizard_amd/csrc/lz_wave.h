@@ -33,6 +33,11 @@ LZ_DEV u32 lz_readlane(u32 v, u32 src) { return (u32)__builtin_amdgcn_readlane((
 // value held by the first active lane, as a scalar.  Used to pin wave-uniform state into SGPRs.
 LZ_DEV u32 lz_uniform(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 
+// `v` with lane `dst` (wave-uniform) replaced by the wave-uniform value x.  Together with lz_readlane this makes a VGPR
+// a 64-entry table that wave-uniform (scalar) code reads and writes without touching memory.  (Compare + select: two
+// VALU ops, like s_mov m0 + v_writelane_b32, which needs M0 for its second scalar operand on gfx9.)
+LZ_DEV u32 lz_writelane(u32 v, u32 x, u32 dst) { return lz_lane() == dst ? x : v; }
+
 // arbitrary cross-lane gather (ds_bpermute_b32): every lane names its own source lane
 LZ_DEV u32 lz_shfl(u32 v, u32 srcLane) { return (u32)__builtin_amdgcn_ds_bpermute((int)(srcLane << 2), (int)v); }
 
@@ -85,6 +90,12 @@ LZ_DEV u32 lz_popc64(u64 m) { return (u32)__builtin_popcountll(m); }
 // LDS atomics (histograms, bit-string assembly); results unused -> ds_add_u32 / ds_or_b32 without return
 LZ_DEV void lz_lds_atomic_add(u32* p, u32 v) { atomicAdd(p, v); }
 LZ_DEV void lz_lds_atomic_or(u32* p, u32 v) { atomicOr(p, v); }
+// LDS words shared by the waves of a workgroup (the Huffman workspace pool): returning OR, AND, and a load the
+// optimiser may not hoist out of a polling loop.
+LZ_DEV u32 lz_lds_atomic_or_rtn(u32* p, u32 v) { return atomicOr(p, v); }
+LZ_DEV void lz_lds_atomic_and(u32* p, u32 v) { atomicAnd(p, v); }
+LZ_DEV u32 lz_lds_poll(const u32* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+LZ_DEV void lz_sleep() { __builtin_amdgcn_s_sleep(8); }
 // Masked bit-field store into an LDS dword, atomic per lane: *p = (*p & ~mask) | val  (ds_mskor_b32).  Lanes of one
 // instruction may target different fields of the same dword.  val must lie inside mask.
 LZ_DEV void lz_lds_mskor(u32* p, u32 mask, u32 val)

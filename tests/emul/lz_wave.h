@@ -93,6 +93,9 @@ LZ_DEV u32 lz_uniform(u32 v)
     return (u32)w->res[me];
 }
 
+// x and dst are wave-uniform; no other lane's state is needed to emulate v_writelane
+LZ_DEV u32 lz_writelane(u32 v, u32 x, u32 dst) { return lz_lane() == dst ? x : v; }
+
 LZ_DEV u32 lz_shfl(u32 v, u32 srcLane)
 {
     lzemu::Wave* w = lzemu::g_wave; int me = w->cur;
@@ -113,6 +116,10 @@ LZ_DEV u32 lz_popc64(u64 m) { return (u32)__builtin_popcountll(m); }
 
 LZ_DEV void lz_lds_atomic_add(u32* p, u32 v) { *p += v; }
 LZ_DEV void lz_lds_atomic_or(u32* p, u32 v) { *p |= v; }
+LZ_DEV u32 lz_lds_atomic_or_rtn(u32* p, u32 v) { const u32 o = *p; *p |= v; return o; }
+LZ_DEV void lz_lds_atomic_and(u32* p, u32 v) { *p &= v; }
+LZ_DEV u32 lz_lds_poll(const u32* p) { return *p; }
+LZ_DEV void lz_sleep() {}
 LZ_DEV void lz_lds_mskor(u32* p, u32 mask, u32 val) { *p = (*p & ~mask) | val; }
 
 LZ_DEV u32 lz_wave_reduce_add(u32 v)
