@@ -370,6 +370,28 @@ def main():
                     best = dt if best is None else min(best, dt)
                 e2e[name] = round(nbe * bs / best / 1e6, 1)
             out["end_to_end"] = e2e
+            # .liz frames of the same sample: LizardGPU_compressFrame (block records assembled on the device; XXH32 on a host thread)
+            import util
+            L.LizardGPU_compressFrameBound.restype = ctypes.c_size_t
+            L.LizardGPU_compressFrameBound.argtypes = [ctypes.c_size_t, ctypes.c_void_p]
+            L.LizardGPU_compressFrame.restype = ctypes.c_size_t
+            L.LizardGPU_compressFrame.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+            fr = {"sample": f"one frame of {nbe * bs} B (256 KiB independent blocks, level 10) from pageable memory, LizardGPU_compressFrame",
+                  "unit": "MB/s"}
+            for name, crc in (("no_content_checksum", 0), ("with_xxh32_content_checksum", 1)):
+                prefs = util.frame_prefs(10, 2, crc, 0)
+                fcap = L.LizardGPU_compressFrameBound(nbe * bs, ctypes.byref(prefs))
+                fbuf = np.empty(fcap, dtype=np.uint8)
+                best = None
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    n = L.LizardGPU_compressFrame(fbuf.ctypes.data, fcap, host.data_ptr(), nbe * bs, ctypes.byref(prefs))
+                    dt = time.perf_counter() - t0
+                    assert n < (1 << 63), "LizardGPU_compressFrame failed"
+                    best = dt if best is None else min(best, dt)
+                fr[name] = round(nbe * bs / best / 1e6, 1)
+                fr["frame_bytes"] = int(n)
+            out["frames"] = fr
         print(json.dumps(out))
     if world > 1:
         L.LizardGPU_commDestroy()

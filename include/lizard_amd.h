@@ -157,6 +157,21 @@ int  LizardGPU_gatherSizes_device(const uint32_t* d_localSizes, size_t nBlocks, 
                                   uint64_t* d_offsets, void* stream);
 int  LizardGPU_commDestroy(void);
 
+/* ---- decompression ----
+ * Independent blocks as Lizard_decompress_safe() decodes them (reference lib/lizard_decompress.h:64, lizard_decompress.c:267;
+ * no dictionary, no prefix): every level's container, huff0 streams, fastLZ4 and LIZv1 codewords.  One wave per block.
+ * _device: block i is d_srcSizes[i] bytes at d_src + i*srcStride (the layout LizardGPU_compressBlocks_device leaves behind)
+ * and is decoded to d_dst + i*dstStride (capacity dstStride); d_outSizes[i] = decoded size, 0xFFFFFFFF if the block is
+ * corrupt or does not fit.  Enqueued on `stream`.  _host: block i is src[offsets[i] .. offsets[i+1]) (the layout of
+ * LizardGPU_compressBlocks_host_packed); synchronous.  LizardGPU_decompress_safe is the one-block twin of
+ * Lizard_decompress_safe: decoded size, or a negative value for a corrupt block / maxDecompressedSize too small.
+ * Memory-safe on any input: never reads outside a compressed block, never writes outside a block's output slot. */
+int LizardGPU_decompressBlocks_device(const void* d_src, size_t srcStride, const uint32_t* d_srcSizes, size_t nBlocks,
+                                      void* d_dst, size_t dstStride, uint32_t* d_outSizes, void* stream);
+int LizardGPU_decompressBlocks_host(const void* src, const uint64_t* offsets, size_t nBlocks, void* dst, size_t dstStride,
+                                    uint32_t* outSizes);
+int LizardGPU_decompress_safe(const char* source, char* dest, int compressedSize, int maxDecompressedSize);
+
 /* Synthetic input, the reference's benchmark generator (programs/datagen.c:153 RDG_genBuffer).
  * Host: fills buffer[0..size) exactly like RDG_genBuffer(buffer, size, matchProba, litProba, seed).
  * Device: block b (b < nBlocks, blockSize bytes each, back to back at d_dst) is

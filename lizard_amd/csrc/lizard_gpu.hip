@@ -15,12 +15,14 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 
 #include "../../include/lizard_amd.h"
 #include "lizard_gpu_shim.h"
 #include "lz_block.h"
 #include "lz_datagen.h"
 #include "lz_pack.h"
+#include "lz_unpack.h"
 
 namespace {
 
@@ -39,11 +41,14 @@ struct LzBatch {
 // Instead ONE workgroup per CU carries W waves and private slices of one allocation; NLDS of them keep their
 // hash table in LDS, the others in a global-memory slot (DESIGN.md section 4 lists the split per level).
 // The splits are compile-time knobs so that tuning variants can be built side by side (lizard_amd/variants).
+// Level 10: all thirteen waves keep their table in LDS.  Three more waves with 16 KiB tables in global memory (12 + 4)
+// were 2.5 % faster but doubled the fabric traffic of a launch (156 GB instead of 77 GB for 27 GB of algorithmic bytes):
+// every put into a global table leaves L2 as a 32-byte write, and the tables' lines are re-fetched at 128 bytes.
 #ifndef LZ_WAVES_FAST
-#define LZ_WAVES_FAST      16
+#define LZ_WAVES_FAST      13
 #endif
 #ifndef LZ_NLDS_FAST
-#define LZ_NLDS_FAST       12
+#define LZ_NLDS_FAST       13
 #endif
 #ifndef LZ_WAVES_FAST_HUF
 #define LZ_WAVES_FAST_HUF  16
@@ -188,6 +193,32 @@ template <bool HUF>
 __global__ __launch_bounds__(64 * LZ_PF22_W) void lz_pricefast18_kernel(LzBatch a)
 {
     lz_wave_main<LZ_PARSER_PRICEFAST, 18, LZ_PF_TAGLOG, HUF, LZ_PF22_W, (HUF ? LZ_HUF_WS_WORDS : (1u << LZ_PF_TAGLOG) / 4u), 0>(a);
+}
+
+// Decompression: one wave per block, same persistent grid; block b is read from
+// src + offsets[b] (packed form) or src + b * srcStride (slot form), srcSizes[b] bytes.
+struct LzUnBatch {
+    const u8* src; const u64* offsets; u64 srcStride; const u32* srcSizes;
+    u8* dst; u64 dstStride; u32* outSizes; u32 nBlocks;
+    u8* scratch; u32* counter;
+};
+#define LZ_WAVES_DEC 16
+__global__ __launch_bounds__(64 * LZ_WAVES_DEC) void lz_decompress_kernel(LzUnBatch a)
+{
+    __shared__ u32 ws[LZ_WAVES_DEC][LZD_WS_WORDS];
+    const u32 wave = lz_uniform(threadIdx.x >> 6);
+    u8* stage = a.scratch + ((u64)blockIdx.x * LZ_MAX_WAVES + wave) * LZ_SCRATCH_BYTES;     // 4 x LZD_STAGE_BYTES fit a scratch slot
+    for (;;) {
+        lz_converge();
+        const u32 b = lz_claim_index(a.counter);
+        if (b >= a.nBlocks) break;
+        const u8* in = a.offsets ? a.src + a.offsets[b] : a.src + (u64)b * a.srcStride;
+        const u32 n = a.offsets ? (u32)(a.offsets[b + 1] - a.offsets[b]) : a.srcSizes[b];
+        const u32 cap = a.dstStride > 0x7E000000ull ? 0x7E000000u : (u32)a.dstStride;
+        const u32 r = lz_decompress_block(in, n, a.dst + (u64)b * a.dstStride, cap, stage, ws[wave]);
+        if (lz_lane() == 0) a.outSizes[b] = r;
+        lz_converge();
+    }
 }
 
 // synthetic input: one thread per block, block b = RDG_genBuffer(blockSize, P, seed0 + b)
@@ -473,6 +504,32 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
     return 0;
 }
 
+int launch_decompress(Ctx& c, const void* d_src, const u64* d_offsets, size_t srcStride, const u32* d_srcSizes, size_t nBlocks,
+                      void* d_dst, size_t dstStride, u32* d_outSizes, hipStream_t stream)
+{
+    if (!d_src || !d_dst || !d_outSizes || (!d_offsets && !d_srcSizes) || nBlocks == 0 || nBlocks > 0xFFFFFFFFu || dstStride == 0) {
+        snprintf(t_err, sizeof t_err, "bad argument (null pointer or zero size)");
+        return -LIZARDGPU_ERR_ARG;
+    }
+    int rc = ctx_init(c);
+    if (rc) return rc;
+    LzUnBatch a;
+    a.src = (const u8*)d_src; a.offsets = d_offsets; a.srcStride = srcStride; a.srcSizes = d_srcSizes;
+    a.dst = (u8*)d_dst; a.dstStride = dstStride; a.outSizes = d_outSizes; a.nBlocks = (u32)nBlocks;
+    a.scratch = c.scratch; a.counter = c.counter;
+    u32 grid = (u32)((nBlocks + LZ_WAVES_DEC - 1) / LZ_WAVES_DEC);
+    if (grid > (u32)c.cus) grid = (u32)c.cus;
+    if (c.timed) LZ_HIP(hipStreamWaitEvent(stream, c.ev1, 0));      // scratch arena and counter are shared with the compress launches
+    LZ_HIP(hipMemsetAsync(c.counter, 0, 4, stream));
+    LZ_HIP(hipEventRecord(c.ev0, stream));
+    hipLaunchKernelGGL(lz_decompress_kernel, dim3(grid), dim3(64 * LZ_WAVES_DEC), 0, stream, a);
+    LZ_HIP(hipGetLastError());
+    LZ_HIP(hipEventRecord(c.ev1, stream));
+    c.timed = true;
+    c.hostKernelMs = -1.0f;
+    return 0;
+}
+
 bool is_pinned_host(const void* p)
 {
     hipPointerAttribute_t at;
@@ -715,6 +772,55 @@ int LizardGPU_compressBlocks_host_packed(const void* src, size_t nBlocks, size_t
     int rc = run_host_job(*g.c, j);
     if (!rc && offsets) offsets[nBlocks] = k.used;
     return rc;
+}
+
+int LizardGPU_decompressBlocks_device(const void* d_src, size_t srcStride, const uint32_t* d_srcSizes, size_t nBlocks,
+                                      void* d_dst, size_t dstStride, uint32_t* d_outSizes, void* stream)
+{
+    Guard g;
+    if (g.rc) return g.rc;
+    return launch_decompress(*g.c, d_src, nullptr, srcStride, d_srcSizes, nBlocks, d_dst, dstStride, d_outSizes, (hipStream_t)stream);
+}
+
+int LizardGPU_decompressBlocks_host(const void* src, const uint64_t* offsets, size_t nBlocks, void* dst, size_t dstStride, uint32_t* outSizes)
+{
+    Guard g;
+    if (g.rc) return g.rc;
+    if (!src || !offsets || !dst || !outSizes || nBlocks == 0 || dstStride == 0) { snprintf(t_err, sizeof t_err, "bad argument"); return -LIZARDGPU_ERR_ARG; }
+    Ctx& c = *g.c;
+    int rc = ctx_init(c);
+    if (rc) return rc;
+    Stage& s = c.stage[0];
+    const size_t inBytes = (size_t)(offsets[nBlocks] - offsets[0]);
+    u64* d_off = nullptr;
+    if ((rc = ensure_dev(&s.d_in, &s.d_in_cap, inBytes + 64))) return rc;
+    if ((rc = ensure_dev(&s.d_slots, &s.d_slots_cap, nBlocks * dstStride))) return rc;
+    if ((rc = ensure_dev(&s.d_packed, &s.d_packed_cap, (nBlocks + 1) * sizeof(u64) + nBlocks * sizeof(u32)))) return rc;   // offsets + sizes ride here
+    d_off = (u64*)s.d_packed;
+    u32* d_out = (u32*)(d_off + nBlocks + 1);
+    std::vector<u64> rel(nBlocks + 1);
+    for (size_t i = 0; i <= nBlocks; i++) rel[i] = offsets[i] - offsets[0];
+    LZ_HIP(hipMemcpyAsync(s.d_in, (const u8*)src + offsets[0], inBytes, hipMemcpyHostToDevice, s.stream));
+    LZ_HIP(hipMemcpyAsync(d_off, rel.data(), (nBlocks + 1) * sizeof(u64), hipMemcpyHostToDevice, s.stream));
+    if ((rc = launch_decompress(c, s.d_in, d_off, 0, nullptr, nBlocks, s.d_slots, dstStride, d_out, s.stream))) return rc;
+    LZ_HIP(hipMemcpyAsync(outSizes, d_out, nBlocks * sizeof(u32), hipMemcpyDeviceToHost, s.stream));
+    LZ_HIP(hipMemcpyAsync(dst, s.d_slots, nBlocks * dstStride, hipMemcpyDeviceToHost, s.stream));
+    LZ_HIP(hipStreamSynchronize(s.stream));
+    return 0;
+}
+
+// twin of Lizard_decompress_safe (reference lib/lizard_decompress.h:64 / lizard_decompress.c:267): one block, host buffers
+int LizardGPU_decompress_safe(const char* source, char* dest, int compressedSize, int maxDecompressedSize)
+{
+    if (compressedSize < 0 || maxDecompressedSize < 0 || !source || !dest) return -1;
+    if (compressedSize == 0) return 0;                          // reference: inputSize < 1 -> 0
+    uint64_t offs[2] = { 0, (uint64_t)compressedSize };
+    uint32_t out = 0;
+    std::vector<char> tmp((size_t)maxDecompressedSize + 1);
+    const int rc = LizardGPU_decompressBlocks_host(source, offs, 1, tmp.data(), (size_t)maxDecompressedSize + 1, &out);
+    if (rc || out == 0xFFFFFFFFu || out > (uint32_t)maxDecompressedSize) return -1;
+    memcpy(dest, tmp.data(), out);
+    return (int)out;
 }
 
 // Internal (lizard_frame_host.c): frame block records — LE32 size word (bit 31 = stored raw) + payload — of nBlocks

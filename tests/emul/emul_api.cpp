@@ -2,6 +2,7 @@
 // bodies (lizard_amd/csrc/lz_block.h, ...) on the CPU SIMT emulator. Loaded by tests via ctypes.
 #include "lz_wave.h"            // tests/emul/lz_wave.h (emulator) — must come first, see the shared guard
 #include "../../lizard_amd/csrc/lz_block.h"
+#include "../../lizard_amd/csrc/lz_unpack.h"
 
 namespace {
 struct Args { const u8* src; u32 n; u8* dst; u32 level; u32* table; u8* tag; u8* scratch; u64* ring; u32 result; u32 tabKind; };
@@ -144,4 +145,29 @@ extern "C" int emul_check_helpers(const void* buf, int n, const unsigned* triple
     lzemu::run_wave(entry_helpers, &a, seed);
     free(a.tmp);
     return (int)a.bad;
+}
+
+
+// One block through the product's decoder body (lz_unpack.h).  Returns the decoded size, -1 = refused.
+namespace {
+struct DecArgs { const u8* in; u32 n; u8* out; u32 cap; u8* stage; u32* ws; u32 result; };
+void entry_dec(void* a)
+{
+    DecArgs* x = (DecArgs*)a;
+    const u32 r = lz_decompress_block(x->in, x->n, x->out, x->cap, x->stage, x->ws);
+    if (lz_lane() == 0) x->result = r;
+}
+}  // namespace
+
+extern "C" int emul_decompress_block(const void* src, int n, void* dst, int cap, unsigned seed)
+{
+    DecArgs a;
+    a.in = (const u8*)src; a.n = (u32)n; a.out = (u8*)dst; a.cap = (u32)cap; a.result = 0;
+    a.stage = (u8*)malloc(4 * LZD_STAGE_BYTES);
+    a.ws = (u32*)malloc(4 * LZD_WS_WORDS);
+    memset(a.stage, 0xDD, 4 * LZD_STAGE_BYTES);
+    memset(a.ws, 0x3C, 4 * LZD_WS_WORDS);
+    lzemu::run_wave(entry_dec, &a, seed);
+    free(a.stage); free(a.ws);
+    return a.result == LZD_ERR ? -1 : (int)a.result;
 }

@@ -16,6 +16,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import util  # noqa: E402
 
 LEVELS = [10, 11, 13, 14, 15, 16, 17, 21, 22, 30, 31, 34, 35, 36, 37, 38, 41, 42]
+P50_64M_KEYS = [(10, 262144), (11, 262144), (21, 262144), (30, 262144), (10, 4 << 20), (10, 65536), (13, 262144), (15, 262144),
+                (17, 262144), (35, 262144), (22, 262144), (31, 262144), (41, 262144), (42, 262144)]
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_vectors.json")
 
 
 def main():
@@ -23,7 +26,11 @@ def main():
     assert ref is not None, "needs /root/reference (build container)"
     dg = util.reference_datagen()
     vec = {"levels": LEVELS, "cases": {}, "frame_style": {}, "p50_64m": {}}
-    for name, data in util.corpus() + util.corpus_long():
+    add_only = "--add-known-answers" in sys.argv          # keep everything recorded, add the missing 64 MiB known answers
+    if add_only:
+        with open(OUT) as f:
+            vec = json.load(f)
+    for name, data in ([] if add_only else util.corpus() + util.corpus_long()):
         entry = {"n": len(data), "input_sha256": util.sha(data), "out": {}}
         for lvl in LEVELS:
             out, r = util.compress_with(ref.Lizard_compress, data, lvl)
@@ -43,7 +50,9 @@ def main():
     dg.RDG_genBuffer(buf, N, 0.5, 0.0, 0)
     vec["p50_64m"]["input_sha256"] = util.sha(buf.raw)
     base = ctypes.addressof(buf)
-    for lvl, bs in [(10, 262144), (11, 262144), (21, 262144), (30, 262144), (10, 4 << 20), (10, 65536), (13, 262144), (15, 262144), (17, 262144), (35, 262144)]:
+    for lvl, bs in P50_64M_KEYS:
+        if f"L{lvl}_B{bs}" in vec["p50_64m"]:
+            continue                                   # --add-known-answers: already recorded
         bound = ref.Lizard_compressBound(bs)
         out = ctypes.create_string_buffer(bound)
         tot, h, sizes = 0, 0, []

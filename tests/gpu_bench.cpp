@@ -51,5 +51,31 @@ int main(int argc, char** argv)
     }
     printf("L%d %zu x %zu: kernel %.3f ms  %.2f GB/s input  ratio %.4f  compressed %llu  verify %s\n", level, nb, bs, ms,
            (double)nb * bs / (ms * 1e-3) / 1e9, (double)nb * bs / (double)tot, tot, bad ? "FAILED" : "ok");
+    if (argc > 7 && argv[7][0] == 'd') {                     // decompress the batch back (slot layout) and compare a sample with the input
+        unsigned char* back = nullptr; uint32_t* osz = nullptr;
+        CK(hipMalloc((void**)&back, nb * bs)); CK(hipMalloc((void**)&osz, nb * 4));
+        double dms = 0;
+        for (int s = -1; s < steps; s++) {
+            int rc = LizardGPU_decompressBlocks_device(dst, stride, sizes, nb, back, bs, osz, nullptr);
+            if (rc) { fprintf(stderr, "decompress launch: %d %s\n", rc, LizardGPU_lastError()); return 2; }
+            const float k = LizardGPU_lastKernelMs();
+            if (s >= 0) dms += k;
+        }
+        dms /= steps;
+        std::vector<uint32_t> ho(nb);
+        CK(hipMemcpy(ho.data(), osz, nb * 4, hipMemcpyDeviceToHost));
+        int dbad = 0;
+        for (size_t i = 0; i < nb; i++) if (ho[i] != bs) dbad++;
+        std::vector<unsigned char> a(bs), b2(bs);
+        for (size_t k = 0; k < 64 && k < nb; k++) {
+            const size_t b = k * (nb - 1) / 63;
+            CK(hipMemcpy(a.data(), src + b * bs, bs, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(b2.data(), back + b * bs, bs, hipMemcpyDeviceToHost));
+            if (memcmp(a.data(), b2.data(), bs)) dbad++;
+        }
+        printf("L%d %zu x %zu: DEcompress kernel %.3f ms  %.2f GB/s output  round trip %s\n", level, nb, bs, dms,
+               (double)nb * bs / (dms * 1e-3) / 1e9, dbad ? "FAILED" : "ok");
+        bad += dbad;
+    }
     return bad ? 1 : 0;
 }
