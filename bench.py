@@ -209,7 +209,7 @@ def main():
     else:
         plan = [(10, 262144, args.blocks or 65536)]
         if not args.headline_only:
-            plan += [(21, 262144, 16384), (30, 262144, 16384), (10, 4 << 20, 4096)]
+            plan += [(21, 262144, 16384), (30, 262144, 16384), (10, 4 << 20, 6656)]
     max_in = max(nb * bs for _, bs, nb in plan)
     max_out = max(nb * ((api.Lizard_compressBound(bs) + 63) & ~63) for _, bs, nb in plan)
     src_all = torch.empty(max_in, dtype=torch.uint8, device=dev)
