@@ -217,6 +217,7 @@ def main():
     stream = torch.cuda.current_stream(dev)
     from lizard_amd.sharding import gather_block_sizes
     threads = max(1, min(96, (os.cpu_count() or 8) - 2))
+    state = {"gather": gather_via}
 
     def sync():
         torch.cuda.synchronize()
@@ -245,11 +246,16 @@ def main():
             api.compress_blocks_device(src, bs, level, dst=dst, sizes=sizes)
             e1.record(stream)
             if world > 1:                                     # RCCL over xGMI: 4 B per block per rank
-                if gather_via.startswith("library"):
-                    _lib.check(L.LizardGPU_gatherSizes_device(sizes.data_ptr(), world * nb, all_sizes.data_ptr(), offsets.data_ptr(),
-                                                               ctypes.c_void_p(stream.cuda_stream)), "LizardGPU_gatherSizes_device")
-                    gathered[0] = (all_sizes, offsets[:-1])
-                else:
+                rc = -1
+                if state["gather"].startswith("library"):
+                    rc = L.LizardGPU_gatherSizes_device(sizes.data_ptr(), world * nb, all_sizes.data_ptr(), offsets.data_ptr(),
+                                                        ctypes.c_void_p(stream.cuda_stream))
+                    if rc == 0:
+                        gathered[0] = (all_sizes, offsets[:-1])
+                    else:                                     # keep the job alive on the collective torch already has (same on every rank)
+                        state["gather"] = "torch.distributed all_gather (library gather failed: %s)" % L.LizardGPU_lastError().decode(errors="replace")
+                        print(f"bench.py rank {rank}: {state['gather']}", file=sys.stderr)
+                if rc != 0:
                     gathered[0] = gather_block_sizes(sizes, world * nb)
             if timed:
                 kernel_ms.append((e0, e1))
@@ -331,7 +337,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": head["workload"], "level": head["level"], "block_size": head["block_size"],
                        "blocks_per_gpu": head["blocks_per_gpu"], "resident_waves": int(L.LizardGPU_residentWaves()),
-                       "size_gather": gather_via},
+                       "size_gather": state["gather"]},
             "ratio": head["ratio"], "compressed_bytes": head["compressed_bytes"],
             "roofline": head["roofline"],
         }

@@ -618,7 +618,20 @@ int stage_fetch(Stage& s, ChunkState& ch)                       // sizes known -
     return 0;
 }
 
+int run_host_job_inner(Ctx& c, const HostJob& j);
 int run_host_job(Ctx& c, const HostJob& j)
+{
+    const int rc = run_host_job_inner(c, j);
+    if (rc) {                                                   // a failed chunk may leave copies of the other stage in flight: drain them
+        char keep[sizeof t_err];
+        memcpy(keep, t_err, sizeof keep);
+        for (Stage& s : c.stage) if (s.stream) (void)hipStreamSynchronize(s.stream);
+        (void)hipGetLastError();
+        memcpy(t_err, keep, sizeof keep);
+    }
+    return rc;
+}
+int run_host_job_inner(Ctx& c, const HostJob& j)
 {
     int rc = ctx_init(c);
     if (rc) return rc;

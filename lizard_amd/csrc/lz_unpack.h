@@ -249,15 +249,36 @@ LZ_DEV bool lzd_huf_decompress(const u8* cSrc, u32 cSize, u8* dst, u32 n, u32* w
         const u32 len = lane == 0 ? l1 : lane == 1 ? l2 : lane == 2 ? l3 : l4;
         const u32 cnt = lane == 3u ? n - 3u * seg : seg;
         u8* o = dst + lane * seg;
-        LzdBits b;
-        if (!lzd_bits_init(b, ip + 6u + off, len)) bad = true;
+        // backward bit reader with a 64-bit register window: acc holds the next `avail` unread bits, left-aligned; refilled
+        // four bytes at a time from the end of the segment towards its start; bits below the start read as zeros
+        const u8* sp = ip + 6u + off;
+        const u32 last = len ? sp[len - 1u] : 0u;
+        if (!last) bad = true;
         else {
+            const u32 hb = 31u - (u32)__builtin_clz(last);       // position of the end mark in the last byte
+            int remaining = (int)(8u * (len - 1u) + hb);         // unread bits of the whole segment
+            u64 acc = 0; u32 avail = 0, bytePos = len;
+            auto refill = [&]() {
+                while (avail <= 32u && bytePos > 0u) {
+                    if (bytePos >= 4u) { acc |= (u64)lz_ld32(sp + bytePos - 4u) << (32u - avail); avail += 32u; bytePos -= 4u; }
+                    else { bytePos--; acc |= (u64)sp[bytePos] << (56u - avail); avail += 8u; }
+                }
+            };
+            refill();
+            acc <<= (8u - hb); avail -= (8u - hb);               // the end mark and the padding above it
+            const u32 shift = 64u - tableLog;
+            u32 four = 0;                                        // four symbols per store
             for (u32 i = 0; i < cnt; i++) {
-                const u32 e = dt[lzd_bits_peek(b, tableLog)];
-                o[i] = (u8)e;
-                b.pos -= (int)(e >> 8);
+                refill();
+                const u32 e = dt[(u32)(acc >> shift)];
+                const u32 nb = e >> 8;
+                four |= (e & 255u) << (8u * (i & 3u));
+                if ((i & 3u) == 3u) { lz_st32(o + i - 3u, four); four = 0; }
+                acc <<= nb; avail = avail > nb ? avail - nb : 0u;
+                remaining -= (int)nb;
             }
-            if (b.pos != 0) bad = true;                          // BIT_endOfDStream: every bit used, none borrowed
+            for (u32 i = cnt & ~3u; i < cnt; i++) o[i] = (u8)(four >> (8u * (i & 3u)));
+            if (remaining != 0) bad = true;                      // BIT_endOfDStream: every bit used, none borrowed
         }
     }
     return lz_ballot(bad) == 0;
