@@ -303,6 +303,15 @@ struct LzTab {
     u16* lo; u8* hi;
     static constexpr bool kSweeps = true;
     static constexpr bool kTagDedup = false;
+    static constexpr bool kXchg = true;                              // get + put of a round in ONE LDS trip, in lane order (lz_lds_mskor_rtn2)
+    // put `ent` into slot h and return the slot's previous value (as seen after the puts of all lower lanes of this instruction)
+    LZ_DEVM u32 xchg(u32 h, u32 ent) const
+    {
+        const u32 sl = (h & 1u) * 16u, sh = (h & 3u) * 8u;
+        u32 ol, oh;
+        lz_lds_mskor_rtn2((u32*)lo + (h >> 1), 0xFFFFu << sl, (ent & 0xFFFFu) << sl, (u32*)hi + (h >> 2), 0xFFu << sh, ((ent >> 16) & 0xFFu) << sh, ol, oh);
+        return ((ol >> sl) & 0xFFFFu) | (((oh >> sh) & 0xFFu) << 16);
+    }
     LZ_DEVM u32  entry(u32 p, u32 first4) const { return (p & 0x1FFFFu) | ((first4 * 2654435761u) >> 25 << 17); }
     LZ_DEVM u32  get(u32 h) const { return (u32)lo[h] | ((u32)hi[h] << 16); }
     LZ_DEVM void set(u32 h, u32 ent) const { lo[h] = (u16)ent; hi[h] = (u8)(ent >> 16); }
@@ -314,8 +323,9 @@ struct LzTab {
     LZ_DEVM void sync() const { lz_lds_sync(); }
 };
 // One extra slot (index 2^HASHLOG, "trash") lets lanes that must not store do so anyway, branch-free.
-#define LZ_TAB_BYTES(HASHLOG) ((3u << (HASHLOG)) + 4u)
-template <int HASHLOG> LZ_DEV LzTab lz_tab_bind(void* mem) { LzTab t; t.lo = (u16*)mem; t.hi = (u8*)mem + (2u << HASHLOG) + 2u; return t; }
+// (both arrays dword-aligned, with room for the trash slot's dword: the exchanges are dword atomics)
+#define LZ_TAB_BYTES(HASHLOG) ((3u << (HASHLOG)) + 8u)
+template <int HASHLOG> LZ_DEV LzTab lz_tab_bind(void* mem) { LzTab t; t.lo = (u16*)mem; t.hi = (u8*)mem + (2u << HASHLOG) + 4u; return t; }
 // Re-stamp every slot that is dead at position Ps (age >= 65536); with `fresh`: all empty.
 template <int HASHLOG>
 LZ_DEV void lz_tab_sweep(const LzTab& t, u32 Ps, bool fresh)
@@ -340,6 +350,8 @@ struct LzTabWide {
     u8* tag;                                                                     // LDS, 2^LZ_WIDE_TAGLOG bytes
     static constexpr bool kSweeps = false;
     static constexpr bool kTagDedup = true;
+    static constexpr bool kXchg = false;
+    LZ_DEVM u32 xchg(u32, u32) const { return 0; }
     LZ_DEVM u32  entry(u32 p, u32 first4) const { return p | ((first4 * 2654435761u) >> 22 << 22); }
     LZ_DEVM u32  get(u32 h) const { return w[h]; }
     LZ_DEVM void set(u32 h, u32 ent) const { w[h] = ent; }
@@ -424,7 +436,16 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
             const u32 first4 = (u32)bytes;
             const u32 h = lz_hash5<HASHLOG>(bytes);
             const u32 mine = table.entry(p, first4);
-            u32 e = table.get(h);                                        // fast.h:86 (value before this round)
+            u32 e;                                                       // fast.h:86: the slot as this visit finds it
+            u64 grp = laneBit;                                           // lanes of this round on my table slot (not needed with kXchg)
+            u32 eOld = 0;
+            if constexpr (TAB::kXchg) {
+                // fast.h:86-88 for all 64 visits in one LDS trip: every lane exchanges its entry into its slot; lanes that share a
+                // slot are served in lane order, so each gets back what the reference's serial walk would have found there.
+                // Visits after the winner never happened: they are taken back once the winner is known (below).
+                e = table.xchg(valid ? h : (1u << HASHLOG), mine);
+            } else {
+            e = table.get(h);                                            // value before this round
             bool lost;
             if constexpr (TAB::kTagDedup) {                              // same-slot lanes found through LDS; nothing stored yet
                 const u32 ti = h & ((1u << LZ_WIDE_TAGLOG) - 1u);
@@ -440,8 +461,7 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
                 lost = valid && table.lostPut(h, mine);
             }
             u64 pend = lz_ballot(lost);                                  // uniform
-            u64 grp = laneBit;                                           // lanes of this round on my table slot
-            const u32 eOld = e;
+            eOld = e;
             if (pend) {
                 while (pend) {
                     const u32 f = lz_ctz64(pend);
@@ -455,6 +475,7 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
                 const u32 j = prev ? 63u - lz_clz64(prev) : lane;
                 const u32 ej = lz_shfl(mine, j);
                 if (prev) e = ej;
+            }
             }
             // accept test, fast.h:90-97 (check bits first: they decide whether any bytes are fetched)
             const u32 age = table.age(p, e);
@@ -500,7 +521,14 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
             u64 commit = validMask;
             if (okMask) { w = lz_ctz64(okMask); commit = validMask & (~0ull >> (63u - w)); }
             // settle the table slots: slots after the winner never happened (the reference stopped there)
-            if constexpr (TAB::kTagDedup) {                              // last committed slot of every group stores, once
+            if constexpr (TAB::kXchg) {
+                // Of the undone lanes on one slot, the lowest one holds in `e` what the slot must go back to (the entry of the last
+                // lane that did happen, or the value from before the round); it is the one whose `e` was not written by an undone
+                // lane: entries of this round are told from older ones by their age (positions of a round ascend).
+                const u32 pw = okMask ? lz_readlane(p, w) : 0u;
+                const bool restore = okMask != 0 && valid && !(commit & laneBit) && table.age(p, e) >= p - pw;
+                table.set(restore ? h : (1u << HASHLOG), e);
+            } else if constexpr (TAB::kTagDedup) {                       // last committed slot of every group stores, once
                 const u64 c = grp & commit;
                 table.set((valid && (c >> lane) == 1ull) ? h : (1u << HASHLOG), mine);
             } else {

@@ -86,6 +86,14 @@ void run_wave(void (*entry)(void*), void* arg, u32 seed)
             break;
         case OP_SYNC:
             break;
+        case OP_MSKOR2:
+            for (int k = 0; k < 2; k++)
+                for (int l = 0; l < LZ_WAVE; l++) {          // one instruction at a time, lanes in ascending order
+                    const u32 old = *w->xp[k][l];
+                    *w->xp[k][l] = (old & ~w->xm[k][l]) | w->xv[k][l];
+                    w->xo[k][l] = old;
+                }
+            break;
         default:
             fprintf(stderr, "lzemu: bad op %d\n", op); abort();
         }
