@@ -111,7 +111,7 @@ LZ_DEV u32 lz_count_fwd(const u8* src, u32 a, u32 b, u32 limit)
         const u32 i = n + 8u * lane;
         u32 c = 0;                                          // equal bytes in my 8, clamped to the limit
         if (a + i < limit) {
-            const u64 x = lz_ld64(src + a + i) ^ lz_ld64(src + b + i);
+            const u64 x = lz_ld64(src + (a + i)) ^ lz_ld64(src + (b + i));
             const u32 room = limit - (a + i);
             c = x ? lz_ctz64(x) >> 3 : 8u;
             c = c < room ? c : room;
@@ -130,7 +130,7 @@ LZ_DEV u32 lz_count_back(const u8* src, u32 P, u32 M, u32 anchor)
     u32 n = 0;                                              // uniform
     for (;;) {
         const u32 i = n + lane + 1u;
-        const bool eq = (P >= anchor + i) && (M >= i) && (src[P - i] == src[M - i]);
+        const bool eq = (P >= anchor + i) && (M >= i) && (src[(P - i)] == src[(M - i)]);
         const u64 ne = lz_ballot(!eq);
         if (ne) return n + lz_ctz64(ne);
         n += 64;
@@ -488,8 +488,8 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
             if (cand) {                                                  // one batch, straight-line (p + 16 <= E - 5)
                 const u32 zb = haveBack ? 8u : 0u, fc = have24 ? 16u : 0u;
                 cA = lz_ld64(src + ep); cB = lz_ld64(src + ep + 8u); pB = lz_ld64(src + p + 8u);
-                cC = lz_ld64(src + ep + fc); pC = lz_ld64(src + p + fc);
-                cZ = lz_ld64(src + ep - zb); pZ = lz_ld64(src + p - zb);
+                cC = lz_ld64(src + (ep + fc)); pC = lz_ld64(src + (p + fc));     // (32-bit offsets from one scalar base: no 64-bit address math)
+                cZ = lz_ld64(src + (ep - zb)); pZ = lz_ld64(src + (p - zb));
             }
             // source bytes for the next round of this run (consumed only if no lane accepts).  Always
             // issued and assigned unconditionally: no select forces the load to complete inside this
