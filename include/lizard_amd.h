@@ -36,8 +36,9 @@ int Lizard_versionNumber(void);
 
 /* reference lib/lizard_compress.h:99 / lib/lizard_compress.c:596.
  * Returns bytes written into dst, 0 on failure (dst too small, level not accelerated, GPU error).
- * Never writes past dst+maxDstSize, never reads outside src[0..srcSize).  (maxDstSize <= 0 returns 0;
- * the reference's room test wraps there, lizard_compress.c:238/:489, and it writes past the buffer.) */
+ * Never writes past dst+maxDstSize, never reads outside src[0..srcSize).  (maxDstSize <= 0 returns 0, where the
+ * reference's room test wraps, lizard_compress.c:238/:489, and it writes past the buffer — with the one exception its own
+ * frame layer produces: a 1-byte block with maxDstSize 0 (lizard_frame.c:461) returns the reference's 6 bytes.) */
 int Lizard_compress(const char* src, char* dst, int srcSize, int maxDstSize, int compressionLevel);
 
 /* reference lib/lizard_compress.h:135 / lib/lizard_compress.c:67 */
@@ -62,9 +63,14 @@ int Lizard_compress_extState_MinLevel(void* state, const char* source, char* des
 Lizard_stream_t* Lizard_resetStream_MinLevel(Lizard_stream_t* streamPtr);
 Lizard_stream_t* Lizard_createStream_MinLevel(void);
 
-/* reference lib/lizard_compress.h:178,198,188 / lib/lizard_compress.c:426,454,550 — linked blocks and
- * dictionaries.  Present so that reference programs link unchanged; NOT implemented on this path (a serial
- * chain between blocks): each returns 0, the reference's failure value, after one message on stderr. */
+/* reference lib/lizard_compress.h:178,198,188 / lib/lizard_compress.c:426,454,550 — streaming ("linked blocks") and
+ * dictionaries.  In the reference a stream is one serial chain (hash table, window and repeat offset carried from call to
+ * call) — nothing a GPU can parallelise.  Implemented HISTORY-FREE: Lizard_compress_continue compresses its block on the GPU
+ * without referring to earlier data (same return contract as Lizard_compress_extState at the stream's level); loadDict and
+ * saveDict do the reference's book-keeping (returned sizes; saveDict copies the last min(dictSize, prefix) bytes of the
+ * previous block into safeBuffer).  Every block is valid for Lizard_decompress_safe_continue / _usingDict — a decoder never
+ * requires a block to use its history — so frames in the frame layer's default linked mode are compressed and decodable;
+ * their bytes are those of independent blocks, not the reference's linked-mode bytes. */
 int Lizard_loadDict(Lizard_stream_t* streamPtr, const char* dictionary, int dictSize);
 int Lizard_saveDict(Lizard_stream_t* streamPtr, char* safeBuffer, int dictSize);
 int Lizard_compress_continue(Lizard_stream_t* streamPtr, const char* src, char* dst, int srcSize, int maxDstSize);

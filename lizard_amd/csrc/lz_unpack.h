@@ -258,10 +258,13 @@ LZ_DEV bool lzd_huf_decompress(const u8* cSrc, u32 cSize, u8* dst, u32 n, u32* w
             const u32 hb = 31u - (u32)__builtin_clz(last);       // position of the end mark in the last byte
             int remaining = (int)(8u * (len - 1u) + hb);         // unread bits of the whole segment
             u64 acc = 0; u32 avail = 0, bytePos = len;
+            u32 nextW = bytePos >= 4u ? lz_ld32(sp + bytePos - 4u) : 0u;     // the next refill word is always requested one refill ahead
             auto refill = [&]() {
                 while (avail <= 32u && bytePos > 0u) {
-                    if (bytePos >= 4u) { acc |= (u64)lz_ld32(sp + bytePos - 4u) << (32u - avail); avail += 32u; bytePos -= 4u; }
-                    else { bytePos--; acc |= (u64)sp[bytePos] << (56u - avail); avail += 8u; }
+                    if (bytePos >= 4u) {
+                        acc |= (u64)nextW << (32u - avail); avail += 32u; bytePos -= 4u;
+                        nextW = bytePos >= 4u ? lz_ld32(sp + bytePos - 4u) : 0u;
+                    } else { bytePos--; acc |= (u64)sp[bytePos] << (56u - avail); avail += 8u; }
                 }
             };
             refill();

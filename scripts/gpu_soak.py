@@ -29,3 +29,4 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 100, (int(sys.argv[
     print('seed', seed, 'done', n, 'bad', bad, '%.0fs' % (time.time()-t0), flush=True)
     if time.time() - t0 > (float(sys.argv[2]) if len(sys.argv) > 2 else 200): break
 print('TOTAL', n, 'bad', bad)
+sys.exit(1 if bad else 0)
