@@ -145,7 +145,7 @@ LZ_DEV void lz_st32(u8* p, u32 v) { reinterpret_cast<lz_u32u*>(p)->v = v; }
 LZ_DEV void lz_st64(u8* p, u64 v) { reinterpret_cast<lz_u64u*>(p)->v = v; }
 // Two masked bit-field EXCHANGES in LDS in one round trip (ds_mskor_rtn_b32 twice, one wait): *pa = (*pa & ~ma) | va and the
 // same for b; oa / ob receive the dwords as they were before this lane's update.  The lanes of one DS atomic instruction that
-// hit the same dword are served in ascending lane order on gfx950 (scripts/micro/lds_atomic_order.hip: 0 violations in
+// hit the same dword are served in ascending lane order on gfx950 (tests/lds_atomic_order.hip: 0 violations in
 // 2.5 M colliding wave-instructions; pinned by tests/test_gpu_parity.py::test_lds_atomics_are_served_in_lane_order): a later lane
 // of a round sees an earlier lane's update — the in-order view of a serial hash-table walk, for free.
 LZ_DEV void lz_lds_mskor_rtn2(u32* pa, u32 ma, u32 va, u32* pb, u32 mb, u32 vb, u32& oa, u32& ob)

@@ -1,4 +1,4 @@
-// Micro-test (run once on the GPU box): do the lanes of ONE wave64 DS atomic instruction that hit the same LDS dword get
+// Device check (tests/test_gpu_parity.py::test_lds_atomics_are_served_in_lane_order): do the lanes of ONE wave64 DS atomic instruction that hit the same LDS dword get
 // processed in ascending lane order?  ds_wrxchg_rtn_b32 and ds_mskor_rtn_b32, random address patterns with many collisions.
 // Prints the number of violations (a returned value that is not the value stored by the closest lower lane on the same word /
 // bit-field, or the initial value when there is none).
@@ -46,10 +46,10 @@ int main()
         for (int l = 0; l < 64; l++) h[t * 64 + l] = (unsigned)(rand() % span) * (mode == 2 ? 32u : 1u) + (mode == 4 ? 0u : (unsigned)(rand() % 2) * 0u);
     }
     unsigned *d, *bad, hb = 0;
-    hipMalloc((void**)&d, trials * 64 * 4); hipMalloc((void**)&bad, 4);
-    hipMemcpy(d, h, trials * 64 * 4, hipMemcpyHostToDevice); hipMemset(bad, 0, 4);
+    (void)hipMalloc((void**)&d, trials * 64 * 4); (void)hipMalloc((void**)&bad, 4);
+    (void)hipMemcpy(d, h, trials * 64 * 4, hipMemcpyHostToDevice); (void)hipMemset(bad, 0, 4);
     hipLaunchKernelGGL(k, dim3(64), dim3(64), 0, 0, d, bad, trials);
-    hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost);
     printf("lds atomic lane-order violations: %u (of %d trials x 2 ops x 64 workgroups)\n", hb, trials);
     return hb != 0;
 }

@@ -209,3 +209,15 @@ def test_device_datagen_matches_host(L):
         got = d.cpu().numpy().tobytes()
         for b in (0, 1, nb // 2, nb - 1):
             assert got[b * bs:(b + 1) * bs] == util.datagen(bs, p, 0.0, 1000 + b), (bs, b, p)
+
+
+def test_lds_atomics_are_served_in_lane_order():
+    """The level 10/30 round (lz_block.h, LzTab::xchg) reads and replaces the table slots of 64 positions with ONE pair of
+    returning DS atomics and relies on the lanes of an instruction that hit the same dword being served in ascending lane
+    order, which is what makes the result equal to the reference's sequential get-then-put (lizard_parser_fast.h:104-118).
+    tests/lds_atomic_order.hip checks exactly that property on the device, 20000 random collision patterns x 64 workgroups."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lds_atomic_order")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "violations: 0 " in r.stdout, r.stdout + r.stderr
