@@ -57,6 +57,9 @@ struct LzBatch {
 #define LZ_NLDS_FAST_HUF   11
 #endif
 #ifndef LZ_HUF_POOL
+#ifndef LZ_HC_POOL
+#define LZ_HC_POOL         3              // chain-build regions (32.3 KiB each) shared by the waves of a hashChain workgroup
+#endif
 #define LZ_HUF_POOL        5              // Huffman workspaces shared by the 16 waves of a level-30 workgroup (0 = one each)
 #endif
 #define LZ_WAVES_FASTLDS      13             // all tables in LDS (blocks above 4 MiB)
@@ -79,7 +82,12 @@ __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
     // POOL != 0: the waves borrow their Huffman workspace from a pool of POOL slots (lz_pool_acquire) instead of owning one
     __shared__ u32 hufPool[POOL ? POOL : 1][POOL ? LZ_HUF_WS_WORDS : 1];
     __shared__ u32 hufPoolMask;
-    if constexpr (POOL != 0) { if (threadIdx.x == 0) hufPoolMask = 0; __syncthreads(); }
+    // hashChain: the chain build of a block borrows one of HCPOOL 32 KiB regions (lz_hc_build)
+    constexpr int HCPOOL = PARSER == LZ_PARSER_HASHCHAIN ? LZ_HC_POOL : 0;
+    static_assert(!(POOL != 0 && HCPOOL != 0), "one pool mask per workgroup");
+    __shared__ u32 hcPoolMem[HCPOOL ? HCPOOL : 1][HCPOOL ? LZ_HC_REGION_WORDS : 1];
+    if constexpr (POOL != 0 || HCPOOL != 0) { if (threadIdx.x == 0) hufPoolMask = 0; __syncthreads(); }
+    LzHufPool hcPool; hcPool.base = &hcPoolMem[0][0]; hcPool.mask = &hufPoolMask; hcPool.count = (u32)HCPOOL; hcPool.stride = LZ_HC_REGION_WORDS;
     constexpr u32 kTagWords = (PARSER == LZ_PARSER_FAST ? (1u << LZ_WIDE_TAGLOG) : (1u << AUX)) / 4u;
     __shared__ u32 wideTags[kOwnTags ? W - NLDS : 1][kOwnTags ? kTagWords : 1];
     const u32 wave = lz_uniform(threadIdx.x >> 6);               // readfirstlane: the wave index (and everything derived from it) lives in SGPRs
@@ -102,7 +110,8 @@ __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
         const u32 n = (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
         const u32 c = lz_compress_block<PARSER, HASHLOG, AUX, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
                                                                   a.level, tableMem, ws, scratch, my.ring, tabKind,
-                                                                  POOL ? &hufPool[0][0] : nullptr, POOL ? &hufPoolMask : nullptr, (u32)POOL);
+                                                                  POOL ? &hufPool[0][0] : nullptr, POOL ? &hufPoolMask : nullptr, (u32)POOL,
+                                                                  &hcPool, (u32)a.blockSize);
         if (lz_lane() == 0) a.sizes[b] = c;
         lz_converge();
     }
@@ -133,12 +142,15 @@ __global__ __launch_bounds__(64 * LZ_WAVES_FAST18) void lz_fast18_kernel(LzBatch
 }
 
 // levels 13-17 / 34-38: hashChain parser (searchLength 5 for rows 13-15, 4 for 16-17; searchNum comes from the
-// level at run time).  Per wave: head table + chain array in global memory, 2 KiB tag array / Huffman workspace in LDS.
+// level at run time).  Per wave: bins + chain array in global memory, Huffman workspace in LDS; the chain build of a
+// block borrows one of LZ_HC_POOL 32 KiB LDS regions of the workgroup.
+#ifndef LZ_WAVES_HC
 #define LZ_WAVES_HC 16
+#endif
 template <bool HUF, int SEARCHLEN>
 __global__ __launch_bounds__(64 * LZ_WAVES_HC) void lz_hashchain_kernel(LzBatch a)
 {
-    lz_wave_main<LZ_PARSER_HASHCHAIN, 18, SEARCHLEN, HUF, LZ_WAVES_HC, (HUF ? LZ_HUF_WS_WORDS : (1u << LZ_HC_TAGLOG) / 4u)>(a);
+    lz_wave_main<LZ_PARSER_HASHCHAIN, 18, SEARCHLEN, HUF, LZ_WAVES_HC, (HUF ? LZ_HUF_WS_WORDS : 1)>(a);
 }
 
 // levels 21 / 41: priceFast + LIZv1, 2^14-slot table.  The parse is a latency chain, so throughput follows the
@@ -455,7 +467,6 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
             if (c.hcSlots) { LZ_HIP(hipDeviceSynchronize()); LZ_HIP(hipFree(c.hcSlots)); c.hcSlots = nullptr; c.hcMaxBlock = 0; }
             const size_t bytes = (size_t)c.cus * LZ_MAX_WAVES * LZ_HC_SLOT_BYTES(cap);
             LZ_HIP(hipMalloc((void**)&c.hcSlots, bytes));
-            LZ_HIP(hipMemset(c.hcSlots, 0, bytes));              // epoch 0 = never used (lz_hc_begin)
             c.hcMaxBlock = cap;
         }
         a.tables = c.hcSlots; a.tableStride = LZ_HC_SLOT_BYTES(c.hcMaxBlock);

@@ -572,15 +572,11 @@ tail:
 LZ_DEV void lz_st24(u8* p, u32 v) { p[0] = (u8)v; p[1] = (u8)(v >> 8); p[2] = (u8)(v >> 16); }
 
 #include "lz_pricefast.h"   // priceFast parser + LIZv1 encoder (uses the helpers above)
-#include "lz_hashchain.h"   // hashChain parser (fastLZ4 codewords through the sequence list)
-
-// ---- sub-block container (reference lib/lizard_compress.c:141-250) -------------------------------
-
-// Huffman workspace pool of a workgroup.  A wave needs its LZ_HUF_WS_WORDS of LDS only while it entropy-codes a sub-block
+// LDS pools of a workgroup (Huffman workspaces; chain-build regions of the hashChain levels).  A wave needs its LZ_HUF_WS_WORDS of LDS only while it entropy-codes a sub-block
 // (about a third of its time at level 30), so the W waves of a workgroup share K < W workspaces and the LDS this frees
 // holds more hash tables.  A wave holding a workspace never waits for anything else: no deadlock; waves that find the pool
 // empty sleep and poll.  mask == nullptr: the wave owns `base` outright.
-struct LzHufPool { u32* base; u32* mask; u32 count; };
+struct LzHufPool { u32* base; u32* mask; u32 count; u32 stride; };   // stride in words
 LZ_DEV u32* lz_pool_acquire(const LzHufPool& pool, u32& slot)
 {
     slot = 0;
@@ -591,7 +587,7 @@ LZ_DEV u32* lz_pool_acquire(const LzHufPool& pool, u32& slot)
         if (freeBits) {
             const u32 bit = freeBits & (0u - freeBits);
             const u32 old = lz_readlane(lz_lds_atomic_or_rtn(pool.mask, lz_lane() == 0 ? bit : 0u), 0);   // branch-free claim, like lz_claim_index
-            if (!(old & bit)) { slot = bit; lz_lds_sync(); return pool.base + (31u - (u32)__builtin_clz(bit)) * LZ_HUF_WS_WORDS; }
+            if (!(old & bit)) { slot = bit; lz_lds_sync(); return pool.base + (31u - (u32)__builtin_clz(bit)) * pool.stride; }
         } else lz_sleep();
     }
 }
@@ -602,6 +598,10 @@ LZ_DEV void lz_pool_release(const LzHufPool& pool, u32 slot)
     lz_lds_atomic_and(pool.mask, lz_lane() == 0 ? ~slot : 0xFFFFFFFFu);
     lz_converge();
 }
+
+#include "lz_hashchain.h"   // hashChain parser (fastLZ4 codewords through the sequence list)
+
+// ---- sub-block container (reference lib/lizard_compress.c:141-250) -------------------------------
 
 // Lizard_writeBlock (reference lib/lizard_compress.c:186-250) over the sequence list of one sub-block.  The stream
 // sizes are known from the parse, so the raw-fallback rule of :201 is decided before a single output byte exists;
@@ -677,7 +677,8 @@ LZ_DEV u32 lz_write_subblock_seq(const u8* src, u32 S, u32 E, u8* op, LzStreams&
 #define LZ_TABKIND_LDS18    2u
 template <int PARSER, int HASHLOG, int AUX, bool HUF>
 LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tableMem, u8* ws, u8* scratch, u64* seqRing,
-                             u32 tabKind = LZ_TABKIND_LDS, u32* hufPoolBase = nullptr, u32* hufPoolMask = nullptr, u32 hufPoolCount = 0)
+                             u32 tabKind = LZ_TABKIND_LDS, u32* hufPoolBase = nullptr, u32* hufPoolMask = nullptr, u32 hufPoolCount = 0,
+                             const LzHufPool* hcPool = nullptr, u32 maxBlock = 0)
 {
     const u32 lane = lz_lane();
     LzStreams st;
@@ -697,8 +698,8 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
     LzHc hc;
     if constexpr (PARSER == LZ_PARSER_HASHCHAIN) {
         const u32 row = (level >= 30u ? level - 21u : level) - 13u;                  // lizard_common.h:240-244, :264-268
-        lz_hc_begin(hc, tableMem, ws, row == 4u ? 256u : 2u << row);
-        lz_hc_build<AUX>(src, n, hc);
+        lz_hc_begin(hc, tableMem, maxBlock, row == 4u ? 256u : 2u << row);
+        lz_hc_build<AUX>(src, n, hc, *hcPool, st);
     }
     else if constexpr (kWide) lz_tab_fresh<HASHLOG>(tabw);
     else if constexpr (PARSER == LZ_PARSER_FAST) {
@@ -717,7 +718,7 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
         const u32 part = (n - pos) < LZ_SUBBLOCK ? (n - pos) : LZ_SUBBLOCK;
         st.nlit = st.nflags = st.noff16 = st.noff24 = 0;      // Lizard_initBlock, :130-138
         st.nseq = 0; st.lastLits = 0;
-        if constexpr (PARSER == LZ_PARSER_HASHCHAIN) lz_parse_hashchain(src, pos, pos + part, hc, st);
+        if constexpr (PARSER == LZ_PARSER_HASHCHAIN) lz_parse_hashchain(src, n, pos, pos + part, hc, st);
         else if constexpr (kWide)                    lz_parse_fast<HASHLOG>(src, pos, pos + part, tabw, st);
         else if constexpr (PARSER == LZ_PARSER_FAST) {
             if (tabKind == LZ_TABKIND_GLOBAL) lz_parse_fast<HASHLOG>(src, pos, pos + part, tabw, st);
@@ -727,7 +728,7 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
         else if (tabKind == LZ_TABKIND_LDS18)  lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, pf18, ws, st);
         else                                   lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, pf24, ws, st);
         {   // Huffman workspace: the wave's own (it doubles as the parser's tag array), or one borrowed from the workgroup's pool
-            LzHufPool pool; pool.base = hufPoolMask ? hufPoolBase : (u32*)ws; pool.mask = hufPoolMask; pool.count = hufPoolCount;
+            LzHufPool pool; pool.base = hufPoolMask ? hufPoolBase : (u32*)ws; pool.mask = hufPoolMask; pool.count = hufPoolCount; pool.stride = LZ_HUF_WS_WORDS;
             op += lz_write_subblock_seq<HUF, kLiz>(src, pos, pos + part, dst + op, st, pool);
         }
         LZ_PROF(st, 5);                                       // container: encode pass / Huffman

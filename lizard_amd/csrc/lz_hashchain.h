@@ -21,9 +21,8 @@
 //     the ring has no aliasing, so a full per-position array is observably the same.  A link the reference
 //     clamps to 65535 because it is longer (":30") ends its walk one step later (":92/:172" leave the
 //     window); here it is stored as 0 = end of chain.  A true distance of exactly 65535 stays usable.
-//   * Head table: 2^18 u32 slots per wave in global memory, never cleared between blocks: a slot holds
-//     (epoch << 22 | position) and counts as empty when the epoch is not the current block's (10-bit epoch
-//     per wave slot, table re-zeroed every 1023 blocks; blocks up to 4 MiB).
+//   * Head table: never exists as a 2^18-slot array.  lz_hc_build brings the positions into hash-bin order and replays
+//     each bin against a 2^12-slot table in LDS (blocks up to 4 MiB: 22-bit positions).
 //   * Phase B: the outer "ip++ until a position has a match" loop (:204-206) runs 64 consecutive positions
 //     per round, each lane walking its own chain until the first candidate that passes the reference's
 //     tests (any such candidate makes ml >= 4 > 0); the first such lane is the position the reference
@@ -38,20 +37,35 @@
 #pragma once
 
 #define LZ_HC_HASHLOG   18
-#define LZ_HC_TAGLOG    11                      // round tag array: 2 KiB of LDS (aliases the Huffman workspace)
 #define LZ_HC_NONE      0x80000000u             // "no head": p - NONE is >= 8 and > 65535 for every block position
-#define LZ_HC_EPOCHS    1024u
 #define LZ_HC_OPTIMAL_ML 18                     // (ML_MASK_LZ4-1)+MINMATCH, hashchain.h:3
-// Per-wave slot in global memory: head table, 64 bytes of persistent metadata (word 0 = epoch of the last
-// block), then prev[] with one u16 per position of the largest block.  The host zeroes a slot once.
-#define LZ_HC_HEAD_BYTES (4u << LZ_HC_HASHLOG)
-#define LZ_HC_SLOT_BYTES(maxBlock) ((size_t)LZ_HC_HEAD_BYTES + 64u + 2u * (size_t)(maxBlock) + 64u)
+// Chain build geometry (lz_hc_build): a block is handled in segments of 2^18 positions; a segment's positions are split
+// into 2^6 bins by the top hash bits, each bin is replayed against a 2^12-slot head table in LDS, and the links return to
+// position order through an LDS window of 2^14 positions.
+#define LZ_HC_SEGLOG    18
+#define LZ_HC_BINLOG    6
+#define LZ_HC_SUBLOG    (LZ_HC_HASHLOG - LZ_HC_BINLOG)
+#define LZ_HC_WINLOG    14
+#define LZ_HC_ARENA_WORDS 8192u                 // 32 KiB: head table, then window
+#define LZ_HC_REGION_WORDS (LZ_HC_ARENA_WORDS + 80u)     // + cursors[64] + a spare word
+// Per-wave slot in global memory (nothing persists from block to block, nothing needs clearing):
+//   bins   u32[2^18]  (hash low bits << 18 | position in segment), bin after bin
+//   links  u32[2^18]  (link << 16 | position in its 2^14 window), in bin order
+//   wins   u32[17*64] cursor of every bin at every window boundary
+//   heads  u32[2^18]  head tables between segments (blocks above 2^18 positions only)
+//   prev   u16[maxBlock]
+#define LZ_HC_BINS_BYTES  (4u << LZ_HC_SEGLOG)
+#define LZ_HC_LINKS_BYTES (4u << LZ_HC_SEGLOG)
+#define LZ_HC_WINS_BYTES  8192u
+#define LZ_HC_HEADS_BYTES(maxBlock) ((size_t)(maxBlock) > (1u << LZ_HC_SEGLOG) ? (size_t)(4u << LZ_HC_HASHLOG) : 0u)
+#define LZ_HC_SLOT_BYTES(maxBlock) ((size_t)LZ_HC_BINS_BYTES + LZ_HC_LINKS_BYTES + LZ_HC_WINS_BYTES + LZ_HC_HEADS_BYTES(maxBlock) + 2u * (size_t)(maxBlock) + 128u)
 
 struct LzHc {
-    u32* head;          // global: 2^18 epoch-tagged slots
+    u32* bins;          // global
+    u32* links;         // global
+    u32* wins;          // global
+    u32* heads;         // global (multi-segment blocks)
     u16* prev;          // global: per block position, distance to the previous head of its bucket (0 = none)
-    u8*  tag;           // LDS: 2^LZ_HC_TAGLOG bytes
-    u32  epoch;         // uniform, 1..1023
     u32  searchNum;     // uniform
 };
 
@@ -62,77 +76,268 @@ LZ_DEV u32 lz_hc_hash(u64 bytes)
     else return lz_hash5<LZ_HC_HASHLOG>(bytes);                                                   // :90-91
 }
 
-// Binds a wave's slot and opens a new epoch (all lanes call).
-LZ_DEV void lz_hc_begin(LzHc& hc, void* slotMem, u8* tag, u32 searchNum)
+// Binds a wave's slot (all lanes call).
+LZ_DEV void lz_hc_begin(LzHc& hc, void* slotMem, u32 maxBlock, u32 searchNum)
 {
-    hc.head = (u32*)slotMem;
-    u32* meta = hc.head + (1u << LZ_HC_HASHLOG);
-    hc.prev = (u16*)(meta + 16);
-    hc.tag = tag;
+    u8* m = (u8*)slotMem;
+    hc.bins = (u32*)m;   m += LZ_HC_BINS_BYTES;
+    hc.links = (u32*)m;  m += LZ_HC_LINKS_BYTES;
+    hc.wins = (u32*)m;   m += LZ_HC_WINS_BYTES;
+    hc.heads = (u32*)m;  m += LZ_HC_HEADS_BYTES(maxBlock);
+    hc.prev = (u16*)m;
     hc.searchNum = searchNum;
-    u32 epoch = lz_uniform(meta[0]) + 1u;
-    if (epoch >= LZ_HC_EPOCHS) {
-        uint4 z; z.x = z.y = z.z = z.w = 0u;
-        for (u32 i = lz_lane() * 4u; i < (1u << LZ_HC_HASHLOG); i += 256u) *(uint4*)(hc.head + i) = z;
-        epoch = 1u;
-    }
-    lz_wave_sync();
-    if (lz_lane() == 0) meta[0] = epoch;
-    lz_converge();
-    hc.epoch = epoch;
 }
 
-// Phase A: Lizard_Insert (hashchain.h:13-43) for every position of the block that has 8 readable bytes.
-// One step = 64 consecutive positions.  Lanes of a step that share a bucket see each other's conditional
-// head updates in position order: such groups (found through the tag array) are replayed with scalar
-// code; the last lane of every group stores the bucket's final head.
-template <int SEARCHLEN>
-LZ_DEV void lz_hc_build(const u8* src, u32 n, const LzHc& hc)
+// Eight source bytes at each of the positions base + 64 k + lane, k = 0..7 (clamped inside the segment; unconditional).
+#ifndef LZ_HC_GRP
+#define LZ_HC_GRP 8u
+#endif
+#ifndef LZ_HC_QUEUE
+#define LZ_HC_QUEUE 16u                          // pass 2: steps between the request of an entry and its use
+#endif
+LZ_DEV void lz_hc_load_src(const u8* sp, u32 base, u32 segLen, u64 (&x)[LZ_HC_GRP])
+{
+    #pragma unroll
+    for (u32 k = 0; k < LZ_HC_GRP; k++) {
+        const u32 p = base + k * 64u + lz_lane();
+        x[k] = lz_ld64(sp + (p < segLen ? p : 0u));
+    }
+}
+
+// 256 words of `links` from lo, four per lane (lane l: lo + 4 l ..; unconditional: words past the range belong to the next
+// bin or, at the very end, to the slot's next area, and are ignored).
+struct __attribute__((packed, aligned(4))) lz_u128a4 { u32 x, y, z, w; };
+LZ_DEV lz_u128a4 lz_hc_load_links(const LzHc& hc, u32 lo)
+{
+    return *(const lz_u128a4*)(hc.links + lo + 4u * lz_lane());
+}
+
+// One step of pass 2: the valid lanes (ascending positions, one bin) read the head of their bucket and become the head —
+// Lizard_Insert's ":38" — through one returning exchange; returns the lane's link (":27-31").  `arena` = the bin's table,
+// slot 2^12 is a spare for the lanes that sit out.
+LZ_DEV u32 lz_hc_visit(u32* arena, bool valid, u32 hl, u32 p)
 {
     const u32 lane = lz_lane();
-    const u64 laneBit = 1ull << lane;
-    const u64 lanesAbove = ~(laneBit | (laneBit - 1ull));
-    const u32 tagMask = (1u << LZ_HC_TAGLOG) - 1u;
-    const u32 nIns = n >= 8u ? n - 7u : 0u;
-    for (u32 base = 0; base < nIns; base += 64u) {
-        const u32 p = base + lane;
-        const bool valid = p < nIns;
-        u32 h = 0, hp = LZ_HC_NONE;
-        if (valid) {
-            h = lz_hc_hash<SEARCHLEN>(lz_ld64(src + p));
-            const u32 e = hc.head[h];
-            if ((e >> 22) == hc.epoch) hp = e & 0x3FFFFFu;
-            hc.tag[h & tagMask] = (u8)lane;
-        }
-        lz_lds_sync();
-        const bool lost = valid && hc.tag[h & tagMask] != (u8)lane;
-        u64 pend = lz_ballot(lost);
-        u64 grp = laneBit;
-        u32 seen = hp;                                           // head as my own insertion sees it
-        u32 after = (p - hp >= LZ_MIN_OFFSET) ? p : hp;          // :38 when alone in the bucket
+    const u32 old = lz_lds_xchg_rtn(arena + (valid ? hl : (1u << LZ_HC_SUBLOG)), p);
+    u32 seen = old;                                              // head as my own insertion sees it
+    u64 pend = lz_ballot(valid && p - old < LZ_MIN_OFFSET);
+    if (pend) {                                                  // ":38" did not happen for some lane: replay its bucket in order
         while (pend) {
-            const u32 f = lz_ctz64(pend);
-            const u32 hv = lz_readlane(h, f);
-            const bool mine = valid && h == hv;
+            const u32 hv = lz_readlane(hl, lz_ctz64(pend));
+            const bool mine = valid && hl == hv;
             const u64 g = lz_ballot(mine);
-            u32 t = lz_readlane(hp, f);                          // bucket head before this step (uniform)
+            u32 t = lz_readlane(old, lz_ctz64(g));               // the bucket's head before this step (uniform)
             for (u64 m = g; m; m &= m - 1ull) {
-                const u32 k = lz_ctz64(m), pk = base + k;
+                const u32 k = lz_ctz64(m), pk = lz_readlane(p, k);
                 if (lane == k) seen = t;
                 t = (pk - t >= LZ_MIN_OFFSET) ? pk : t;
-                if (lane == k) after = t;
             }
-            if (mine) grp = g;
+            if (mine && lane == 63u - lz_clz64(g)) arena[hl] = t;
             pend &= ~g;
         }
-        lz_lds_sync();                                           // tag reads done before the next step's writes
-        if (valid) {
-            const u32 d = p - seen;
-            hc.prev[p] = (u16)(d <= LZ_MAX_DIST_LZ4 ? d : 0u);   // :27-31
-            if ((grp & lanesAbove) == 0) hc.head[h] = (hc.epoch << 22) | after;
-        }
-        lz_wave_sync();                                          // head stores before the next step's loads
+        lz_lds_sync();
     }
+    const u32 d = p - seen;
+    return d <= LZ_MAX_DIST_LZ4 ? d : 0u;
+}
+
+// Phase A: Lizard_Insert (hashchain.h:13-43) for every position of the block that has 8 readable bytes:
+//     prev[p] = p - head[h(p)]  (0 when farther than 65535, :27-31);   if (p - head[h(p)] >= MIN_OFFSET) head[h(p)] = p  (:38)
+// in position order.  The head table (2^18 slots) does not fit LDS and a table in global memory costs a 128-byte fabric read
+// and a 32-byte fabric write per position, so the positions are first brought into an order in which a small table is enough:
+//   pass 0  histogram of the top 6 hash bits (LDS counters);
+//   pass 1  stable partition into 64 bins: ONE returning LDS add per step hands every lane its slot in its bin — lanes of a
+//           DS atomic are served in lane order (lz_wave.h), so a bin keeps position order; the entries go straight to their
+//           slots (a bin's 128-byte line is complete ~32 steps later and is merged in L2); the cursors at every
+//           2^14-position boundary are noted;
+//   pass 2  bin after bin against a 2^12-slot head table in LDS: ONE returning LDS exchange per step is "read the head, become
+//           the head" in position order.  That is :38 whenever the distance is >= MIN_OFFSET; a step in which some lane finds
+//           its head closer than that (runs) replays the affected buckets with scalar code, exactly, before the next step.
+//           The link goes to `links`, in bin order;
+//   pass 3  windows of 2^14 positions: every bin's entries of the window (a contiguous, known range) drop their link into an
+//           LDS window at their position; the window leaves as prev[], coalesced.
+// Blocks above 2^18 positions run segment after segment; the head tables travel through `heads` in between.
+// The LDS region (32.3 KiB) is borrowed from the workgroup's pool for the duration of the build.
+template <int SEARCHLEN>
+LZ_DEV void lz_hc_build(const u8* src, u32 n, const LzHc& hc, const LzHufPool& pool, LzStreams& st)
+{
+    const u32 lane = lz_lane();
+    const u32 nIns = n >= 8u ? n - 7u : 0u;
+    if (!nIns) return;
+    u32 poolSlot;
+    u32* const arena = lz_pool_acquire(pool, poolSlot);
+    LZ_PROF(st, 7);                                              // (instrumented build) waiting for a region
+    u32* const cur = arena + LZ_HC_ARENA_WORDS;                  // [0..63] cursors, [64] spare
+    u16* const win16 = (u16*)arena;
+    constexpr u32 kSeg = 1u << LZ_HC_SEGLOG, kSub = 1u << LZ_HC_SUBLOG, kWin = 1u << LZ_HC_WINLOG;
+    for (u32 seg = 0; seg < nIns; seg += kSeg) {
+        const u32 segLen = (nIns - seg) < kSeg ? (nIns - seg) : kSeg;
+        const bool firstSeg = seg == 0u, lastSeg = seg + segLen >= nIns;
+        const u8* const sp = src + seg;
+        // Source bytes are requested one group of 8 steps (512 positions) ahead of their use: the passes are chains of LDS
+        // trips, and a memory round trip per step would be all they wait for.
+        // ---- pass 0: bin sizes ----
+        cur[lane] = 0u; if (lane == 0) cur[64] = 0u;
+        lz_lds_sync();
+        {
+            u64 x[LZ_HC_GRP], y[LZ_HC_GRP];
+            lz_hc_load_src(sp, 0u, segLen, x);
+            for (u32 base = 0; base < segLen; base += 64u * LZ_HC_GRP) {
+                lz_hc_load_src(sp, base + 64u * LZ_HC_GRP, segLen, y);
+                #pragma unroll
+                for (u32 k = 0; k < LZ_HC_GRP; k++) {
+                    const u32 p = base + k * 64u + lane;
+                    const u32 h = lz_hc_hash<SEARCHLEN>(x[k]);
+                    lz_lds_atomic_add(cur + (p < segLen ? h >> LZ_HC_SUBLOG : 64u), 1u);
+                    x[k] = y[k];
+                }
+            }
+        }
+        lz_lds_sync();
+        LZ_PROF(st, 11);                                         // pass 0
+        const u32 cnt = cur[lane];
+        const u32 myStart = lz_wave_scan_excl_add(cnt), myEnd = myStart + cnt;     // lane b: range of bin b in `bins`
+        lz_lds_sync();
+        cur[lane] = myStart;
+        hc.wins[lane] = myStart;
+        lz_lds_sync();
+        // ---- pass 1: stable partition ----
+        {
+            u64 x[LZ_HC_GRP], y[LZ_HC_GRP];
+            lz_hc_load_src(sp, 0u, segLen, x);
+            for (u32 base4 = 0; base4 < segLen; base4 += 64u * LZ_HC_GRP) {
+                lz_hc_load_src(sp, base4 + 64u * LZ_HC_GRP, segLen, y);
+                #pragma unroll
+                for (u32 k = 0; k < LZ_HC_GRP; k++) {
+                    const u32 base = base4 + k * 64u;
+                    if (base < segLen) {                             // uniform
+                        if (base && !(base & (kWin - 1u))) hc.wins[(base >> LZ_HC_WINLOG) * 64u + lane] = cur[lane];
+                        const u32 p = base + lane;
+                        const bool valid = p < segLen;
+                        const u32 h = lz_hc_hash<SEARCHLEN>(x[k]);
+                        const u32 bin = valid ? h >> LZ_HC_SUBLOG : 64u;
+                        const u32 s = lz_lds_add_rtn(cur + bin, 1u);
+                        if (valid) hc.bins[s] = ((h & (kSub - 1u)) << LZ_HC_SEGLOG) | p;    // a bin's line fills within ~32 steps: merged in L2
+                    }
+                    x[k] = y[k];
+                }
+            }
+        }
+        hc.wins[((segLen + kWin - 1u) >> LZ_HC_WINLOG) * 64u + lane] = myEnd;
+        lz_wave_sync();                                          // bins are in memory; the arena changes hands
+        LZ_PROF(st, 12);                                         // pass 1
+        // ---- pass 2: heads and links, bin after bin ----
+        // The entries of all bins lie back to back, so they are read on a flat grid of 64 (sixteen steps ahead); a step that
+        // straddles a bin border is served part by part, with the table changing hands in between.
+        {
+            const u32 nSteps = (segLen + 63u) >> 6;
+            u32 b = 0, bEnd = lz_readlane(myEnd, 0);                 // current bin and its end (uniform)
+            bool fresh = true;                                       // the current bin's table is not set up yet
+            u32 q[LZ_HC_QUEUE];                                      // entries of the next 16 steps
+            #pragma unroll
+            for (u32 k = 0; k < LZ_HC_QUEUE; k++) { const u32 nx = k * 64u + lane; q[k] = hc.bins[nx < segLen ? nx : 0u]; }
+            for (u32 j8 = 0; j8 < nSteps; j8 += LZ_HC_QUEUE)
+            #pragma unroll
+            for (u32 k = 0; k < LZ_HC_QUEUE; k++) {
+                const u32 j = j8 + k;
+                if (j < nSteps) {                                    // uniform
+                const u32 e0 = q[k];
+                { const u32 nx = (j + LZ_HC_QUEUE) * 64u + lane; q[k] = hc.bins[nx < segLen ? nx : 0u]; }
+                const u32 idx = j * 64u + lane, stepEnd = (j + 1u) * 64u < segLen ? (j + 1u) * 64u : segLen;
+                const u32 hl = e0 >> LZ_HC_SEGLOG, p = seg + (e0 & (kSeg - 1u));
+                u32 link;
+                if (!fresh && bEnd >= stepEnd)                       // the whole step lies in the current bin: straight-line code
+                    link = lz_hc_visit(arena, idx < stepEnd, hl, p);
+                else {
+                    u32 from = j * 64u;                              // first entry of this step not served yet (uniform)
+                    link = 0;
+                    while (from < stepEnd) {
+                        while (bEnd <= from) {                       // leave bins that end here (also empty ones)
+                            if (!lastSeg) {
+                                if (fresh) { uint4 none; none.x = none.y = none.z = none.w = LZ_HC_NONE;
+                                             if (firstSeg) for (u32 i = lane * 4u; i < kSub; i += 256u) *(uint4*)(hc.heads + b * kSub + i) = none; }
+                                else { lz_lds_sync(); for (u32 i = lane * 4u; i < kSub; i += 256u) *(uint4*)(hc.heads + b * kSub + i) = *(const uint4*)(arena + i); }
+                            }
+                            b++; bEnd = lz_readlane(myEnd, b & 63u); fresh = true;
+                        }
+                        if (fresh) {
+                            lz_lds_sync();                           // the previous table's reads are done
+                            if (firstSeg) { uint4 none; none.x = none.y = none.z = none.w = LZ_HC_NONE;
+                                            for (u32 i = lane * 4u; i < kSub; i += 256u) *(uint4*)(arena + i) = none; }
+                            else for (u32 i = lane * 4u; i < kSub; i += 256u) *(uint4*)(arena + i) = *(const uint4*)(hc.heads + b * kSub + i);
+                            lz_lds_sync();
+                            fresh = false;
+                        }
+                        const u32 to = bEnd < stepEnd ? bEnd : stepEnd;
+                        const bool valid = idx >= from && idx < to;
+                        const u32 l = lz_hc_visit(arena, valid, hl, p);
+                        if (valid) link = l;
+                        from = to;
+                    }
+                }
+                if (idx < segLen) hc.links[idx] = (link << 16) | (e0 & (kWin - 1u));     // link | position in its window
+                }
+            }
+            if (!lastSeg) {                                          // the bins from the current one on
+                for (;;) {
+                    if (fresh) { uint4 none; none.x = none.y = none.z = none.w = LZ_HC_NONE;
+                                 if (firstSeg) for (u32 i = lane * 4u; i < kSub; i += 256u) *(uint4*)(hc.heads + b * kSub + i) = none; }
+                    else { lz_lds_sync(); for (u32 i = lane * 4u; i < kSub; i += 256u) *(uint4*)(hc.heads + b * kSub + i) = *(const uint4*)(arena + i); }
+                    if (++b >= 64u) break;
+                    fresh = true;
+                }
+            }
+            lz_lds_sync();
+        }
+        lz_wave_sync();                                          // links (and wins) are in memory
+        LZ_PROF(st, 13);                                         // pass 2
+        // ---- pass 3: back to position order ----
+        const u32 nWin = (segLen + kWin - 1u) >> LZ_HC_WINLOG;
+        for (u32 w = 0; w < nWin; w++) {
+            const u32 wLo = hc.wins[w * 64u + lane], wHi = hc.wins[(w + 1u) * 64u + lane];
+            const u32 wBase = w << LZ_HC_WINLOG;
+            lz_u128a4 q[LZ_HC_GRP];                                  // the next 8 bins' words, in flight
+            u64 more = 0;                                            // bins with more than 256 entries in this window (uniform)
+            #pragma unroll
+            for (u32 k = 0; k < LZ_HC_GRP; k++) q[k] = lz_hc_load_links(hc, lz_readlane(wLo, k));
+            for (u32 b8 = 0; b8 < 64u; b8 += LZ_HC_GRP)
+            #pragma unroll
+            for (u32 k = 0; k < LZ_HC_GRP; k++) {
+                const u32 b = b8 + k;
+                const u32 lo = lz_readlane(wLo, b), hi = lz_readlane(wHi, b);
+                lz_u128a4 v = q[k];
+                q[k] = lz_hc_load_links(hc, lz_readlane(wLo, (b + LZ_HC_GRP) & 63u));
+                {   // straight-line: a loop here makes the compiler wait for every load in flight
+                    const u32 idx = lo + 4u * lane;
+                    if (idx < hi)      win16[v.x & (kWin - 1u)] = (u16)(v.x >> 16);
+                    if (idx + 1u < hi) win16[v.y & (kWin - 1u)] = (u16)(v.y >> 16);
+                    if (idx + 2u < hi) win16[v.z & (kWin - 1u)] = (u16)(v.z >> 16);
+                    if (idx + 3u < hi) win16[v.w & (kWin - 1u)] = (u16)(v.w >> 16);
+                }
+                if (hi - lo > 256u) more |= 1ull << b;               // a bin with more than 256 entries in the window: below
+            }
+            while (more) {                                           // skewed data only
+                const u32 b = lz_ctz64(more); more &= more - 1ull;
+                const u32 lo = lz_readlane(wLo, b), hi = lz_readlane(wHi, b);
+                for (u32 i = lo + 256u; i < hi; i += 256u) {
+                    const u32 idx = i + 4u * lane;
+                    const lz_u128a4 v = lz_hc_load_links(hc, i);
+                    if (idx < hi)      win16[v.x & (kWin - 1u)] = (u16)(v.x >> 16);
+                    if (idx + 1u < hi) win16[v.y & (kWin - 1u)] = (u16)(v.y >> 16);
+                    if (idx + 2u < hi) win16[v.z & (kWin - 1u)] = (u16)(v.z >> 16);
+                    if (idx + 3u < hi) win16[v.w & (kWin - 1u)] = (u16)(v.w >> 16);
+                }
+            }
+            lz_lds_sync();
+            const u32 wLen = (segLen - wBase) < kWin ? (segLen - wBase) : kWin;
+            for (u32 o = lane * 8u; o < wLen; o += 512u)        // 16 bytes per lane; the tail may carry stale cells past nIns (never read)
+                *(uint4*)(hc.prev + seg + wBase + o) = *(const uint4*)(win16 + o);
+            lz_lds_sync();
+        }
+        lz_wave_sync();
+        LZ_PROF(st, 14);                                         // pass 3
+    }
+    lz_pool_release(pool, poolSlot);
 }
 
 // One search of the chain that starts at X (uniform).  wider == false: Lizard_InsertAndFindBestMatch
@@ -143,7 +348,7 @@ LZ_DEV void lz_hc_build(const u8* src, u32 n, const LzHc& hc)
 // and 8 bytes backward with lane-local loads.  Lanes whose comparison is still open after that (long
 // matches) are finished one at a time with the wave-wide helpers, skipping those that cannot reach the
 // best length any more.  "First strictly longer candidate in chain order" == maximum length, lowest lane.
-LZ_DEV u32 lz_hc_search(const u8* src, const LzHc& hc, u32 X, u32 iLow, u32 iHigh, u32 longest, bool wider, u32& ref, u32& start, LzStreams& st)
+LZ_DEV u32 lz_hc_search(const u8* src, u32 nBlock, const LzHc& hc, u32 X, u32 iLow, u32 iHigh, u32 longest, bool wider, u32& ref, u32& start, LzStreams& st)
 {
     const u32 lane = lz_lane();
     const u32 first4 = lz_ld32(src + X);
@@ -163,9 +368,10 @@ LZ_DEV u32 lz_hc_search(const u8* src, const LzHc& hc, u32 X, u32 iLow, u32 iHig
         }
         left -= cnt;
         LZ_PROF(st, 8);                                          // (instrumented build) chain walk
-        const bool ok = lane < cnt && X - cand >= LZ_MIN_OFFSET && lz_ld32(src + cand) == first4;   // :73 / :146
+        // The 4-byte test first: few candidates pass it, and what they read next lies in the line the test just fetched.
         u32 mlt = 0, bk = 0;
         bool open = false;                                       // my comparison needs the wave-wide helpers
+        const bool ok = lane < cnt && X - cand >= LZ_MIN_OFFSET && lz_ld32(src + cand) == first4;
         if (ok) {
             u32 f = 4u;
             bool eq = true;
@@ -223,7 +429,7 @@ LZ_DEV u32 lz_hc_search(const u8* src, const LzHc& hc, u32 X, u32 iLow, u32 iHig
 }
 
 // Sub-block [S,E) of the block at src (hashchain.h:188-369).  The chain must have been built for the block.
-LZ_DEV void lz_parse_hashchain(const u8* src, u32 S, u32 E, const LzHc& hc, LzStreams& st)
+LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const LzHc& hc, LzStreams& st)
 {
     const u32 lane = lz_lane();
     int anchor = (int)S, ip = (int)S + 1;                        // uniform; :201
@@ -258,12 +464,12 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 S, u32 E, const LzHc& hc, LzSt
             ip += (int)lz_popc64(lz_ballot(valid));
         }
         LZ_PROF(st, 0);
-        ml = (int)lz_hc_search(src, hc, (u32)ip, (u32)ip, (u32)matchlimit, 0u, false, ref, dummy, st);
+        ml = (int)lz_hc_search(src, nBlock, hc, (u32)ip, (u32)ip, (u32)matchlimit, 0u, false, ref, dummy, st);
         LZ_PROF(st, 1);
         start0 = ip; ref0 = ref; ml0 = ml;                                                        // :209
     search2:
         if (ip + ml < mflimit)                                                                    // :212-214
-            ml2 = (int)lz_hc_search(src, hc, (u32)(ip + ml - 2), (u32)(ip + 1), (u32)matchlimit, (u32)ml, true, ref2, start2, st);
+            ml2 = (int)lz_hc_search(src, nBlock, hc, (u32)(ip + ml - 2), (u32)(ip + 1), (u32)matchlimit, (u32)ml, true, ref2, start2, st);
         else ml2 = ml;
         LZ_PROF(st, 2);
         if (ml2 == ml) {                                                                          // :216-219
@@ -292,7 +498,7 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 S, u32 E, const LzHc& hc, LzSt
             if (correction > 0) { start2 += (u32)correction; ref2 += (u32)correction; ml2 -= correction; }
         }
         if ((int)start2 + ml2 < mflimit)                                                          // :263-265
-            ml3 = (int)lz_hc_search(src, hc, start2 + (u32)ml2 - 3u, start2, (u32)matchlimit, (u32)ml2, true, ref3, start3, st);
+            ml3 = (int)lz_hc_search(src, nBlock, hc, start2 + (u32)ml2 - 3u, start2, (u32)matchlimit, (u32)ml2, true, ref3, start3, st);
         else ml3 = ml2;
         LZ_PROF(st, 3);
         if (ml3 == ml2) {                                                                         // :267-275

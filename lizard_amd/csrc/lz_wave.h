@@ -155,6 +155,22 @@ LZ_DEV void lz_lds_mskor_rtn2(u32* pa, u32 ma, u32 va, u32* pb, u32 mb, u32 vb, 
                  : "v"((u32)(uintptr_t)pa), "v"(ma), "v"(va), "v"((u32)(uintptr_t)pb), "v"(mb), "v"(vb) : "memory");
 }
 
+// Returning exchange / add on an LDS dword; every lane of the wave takes part (lanes with nothing to do aim at a spare word).
+// Lane order as above: lane l receives what the closest lower lane of the same dword left behind — lz_lds_add_rtn with 1 hands
+// out consecutive slots in lane order (a stable partition step), lz_lds_xchg_rtn is "read the head, become the head".
+LZ_DEV u32 lz_lds_xchg_rtn(u32* p, u32 v)
+{
+    u32 o;
+    asm volatile("ds_wrxchg_rtn_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(o) : "v"((u32)(uintptr_t)p), "v"(v) : "memory");
+    return o;
+}
+LZ_DEV u32 lz_lds_add_rtn(u32* p, u32 v)
+{
+    u32 o;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(o) : "v"((u32)(uintptr_t)p), "v"(v) : "memory");
+    return o;
+}
+
 // One-pass stream traffic (sequence list, the encode pass's literal re-reads, the output streams): with
 // -DLZ_NT_STREAMS these carry the `nt` hint so that they do not displace the hash tables that live in L2.
 #ifdef LZ_NT_STREAMS

@@ -5,30 +5,30 @@
 #include "../../lizard_amd/csrc/lz_unpack.h"
 
 namespace {
-struct Args { const u8* src; u32 n; u8* dst; u32 level; u32* table; u8* tag; u8* scratch; u64* ring; u32 result; u32 tabKind; };
+struct Args { const u8* src; u32 n; u8* dst; u32 level; u32* table; u8* tag; u8* scratch; u64* ring; u32 result; u32 tabKind; u32* hcRegion; u32 maxBlock; u32 poolMask; };
 
 template <int PARSER, int HASHLOG, int AUX, bool HUF>
 void entry_block(void* a)
 {
     Args* x = (Args*)a;
-    u32 r = lz_compress_block<PARSER, HASHLOG, AUX, HUF>(x->src, x->n, x->dst, x->level, x->table, x->tag, x->scratch, x->ring, x->tabKind);
+    LzHufPool hcPool; hcPool.base = x->hcRegion; hcPool.mask = &x->poolMask; hcPool.count = 1; hcPool.stride = LZ_HC_REGION_WORDS;   // a pool of one chain-build region
+    u32 r = lz_compress_block<PARSER, HASHLOG, AUX, HUF>(x->src, x->n, x->dst, x->level, x->table, x->tag, x->scratch, x->ring, x->tabKind,
+                                                         nullptr, nullptr, 0, &hcPool, x->maxBlock);
     if (lz_lane() == 0) x->result = r;
 }
 }  // namespace
 
 
 
-// hashChain levels keep one persistent, zero-initialised global slot (as the host library does), so the
-// epoch logic of lz_hc_begin is exercised across calls; emul_hc_set_epoch lets a test jump to the wrap.
+// hashChain levels keep one persistent global slot that is never cleared (as the host library does): whatever an earlier
+// block left in it (bins, links, saved head tables) must not matter.
 static u8* g_hcSlot = nullptr;
 static const size_t kHcMaxBlock = 4u << 20;
 static u8* hc_slot()
 {
-    if (!g_hcSlot) g_hcSlot = (u8*)calloc(1, LZ_HC_SLOT_BYTES(kHcMaxBlock));
+    if (!g_hcSlot) { g_hcSlot = (u8*)malloc(LZ_HC_SLOT_BYTES(kHcMaxBlock)); memset(g_hcSlot, 0xB7, LZ_HC_SLOT_BYTES(kHcMaxBlock)); }
     return g_hcSlot;
 }
-extern "C" void emul_hc_set_epoch(unsigned e) { ((u32*)hc_slot())[1u << LZ_HC_HASHLOG] = e; }
-extern "C" unsigned emul_hc_get_epoch(void) { return ((u32*)hc_slot())[1u << LZ_HC_HASHLOG]; }
 
 // Compress one block with the emulated wave. dst must hold Lizard_compressBound(n) bytes.
 // `seed` drives the lane scheduling order (any value must give identical output).
@@ -57,6 +57,9 @@ extern "C" int emul_compress_block(const void* src, int n, void* dst, int level,
     const bool huf = level >= 30;
     void* garbageTable = a.table;
     if (hcLevel) a.table = (u32*)hc_slot();
+    a.maxBlock = (u32)kHcMaxBlock; a.poolMask = 0;
+    a.hcRegion = (u32*)aligned_alloc(64, 4 * LZ_HC_REGION_WORDS + 64);
+    memset(a.hcRegion, 0x3C, 4 * LZ_HC_REGION_WORDS);
     switch (base) {
     case 13: case 14: case 15: lzemu::run_wave(huf ? entry_block<LZ_PARSER_HASHCHAIN, 18, 5, true> : entry_block<LZ_PARSER_HASHCHAIN, 18, 5, false>, &a, seed); break;
     case 16: case 17:          lzemu::run_wave(huf ? entry_block<LZ_PARSER_HASHCHAIN, 18, 4, true> : entry_block<LZ_PARSER_HASHCHAIN, 18, 4, false>, &a, seed); break;
@@ -65,7 +68,7 @@ extern "C" int emul_compress_block(const void* src, int n, void* dst, int level,
     case 21: lzemu::run_wave(huf ? entry_block<LZ_PARSER_PRICEFAST, 14, 12, true> : entry_block<LZ_PARSER_PRICEFAST, 14, 12, false>, &a, seed); break;
     default: lzemu::run_wave(huf ? entry_block<LZ_PARSER_PRICEFAST, 18, 12, true> : entry_block<LZ_PARSER_PRICEFAST, 18, 12, false>, &a, seed); break;
     }
-    free(garbageTable); free(a.tag); free(a.scratch);
+    free(garbageTable); free(a.tag); free(a.scratch); free(a.hcRegion);
     return (int)a.result;
 }
 

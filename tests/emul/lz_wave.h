@@ -36,7 +36,7 @@ namespace lzemu {
 
 extern "C" void lzemu_ctx_switch(void** save_sp, void* load_sp);
 
-enum Op { OP_NONE = 0, OP_BALLOT, OP_READLANE, OP_UNIFORM, OP_SHFL, OP_SYNC, OP_MSKOR2, OP_DONE };
+enum Op { OP_NONE = 0, OP_BALLOT, OP_READLANE, OP_UNIFORM, OP_SHFL, OP_SYNC, OP_MSKOR2, OP_ATOM1, OP_DONE };
 
 struct Wave {
     void*  lane_sp[LZ_WAVE];
@@ -132,6 +132,17 @@ LZ_DEV void lz_lds_mskor_rtn2(u32* pa, u32 ma, u32 va, u32* pb, u32 mb, u32 vb, 
     oa = w->xo[0][me]; ob = w->xo[1][me];
 }
 LZ_DEV void lz_lds_mskor(u32* p, u32 mask, u32 val) { *p = (*p & ~mask) | val; }
+// returning exchange (kind 0) / add (kind 1), all lanes take part, served in ascending lane order
+LZ_DEV u32 lz_lds_atom1(u32* p, u32 v, u32 kind)
+{
+    lzemu::Wave* w = lzemu::g_wave; int me = w->cur;
+    w->xp[0][me] = p; w->xm[0][me] = kind; w->xv[0][me] = v;
+    lzemu::park(lzemu::OP_ATOM1);
+    return w->xo[0][me];
+}
+LZ_DEV u32 lz_lds_xchg_rtn(u32* p, u32 v) { return lz_lds_atom1(p, v, 0u); }
+LZ_DEV u32 lz_lds_add_rtn(u32* p, u32 v) { return lz_lds_atom1(p, v, 1u); }
+
 
 LZ_DEV u32 lz_wave_reduce_add(u32 v)
 {

@@ -94,6 +94,13 @@ void run_wave(void (*entry)(void*), void* arg, u32 seed)
                     w->xo[k][l] = old;
                 }
             break;
+        case OP_ATOM1:
+            for (int l = 0; l < LZ_WAVE; l++) {              // lanes in ascending order
+                const u32 old = *w->xp[0][l];
+                *w->xp[0][l] = w->xm[0][l] ? old + w->xv[0][l] : w->xv[0][l];
+                w->xo[0][l] = old;
+            }
+            break;
         default:
             fprintf(stderr, "lzemu: bad op %d\n", op); abort();
         }

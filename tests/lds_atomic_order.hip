@@ -1,5 +1,5 @@
 // Device check (tests/test_gpu_parity.py::test_lds_atomics_are_served_in_lane_order): do the lanes of ONE wave64 DS atomic instruction that hit the same LDS dword get
-// processed in ascending lane order?  ds_wrxchg_rtn_b32 and ds_mskor_rtn_b32, random address patterns with many collisions.
+// processed in ascending lane order?  ds_wrxchg_rtn_b32, ds_mskor_rtn_b32 and ds_add_rtn_u32, random address patterns with many collisions.
 // Prints the number of violations (a returned value that is not the value stored by the closest lower lane on the same word /
 // bit-field, or the initial value when there is none).
 #include <hip/hip_runtime.h>
@@ -33,6 +33,15 @@ __global__ void k(const unsigned* addr, unsigned* bad, int trials)
         asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3\n s_waitcnt lgkmcnt(0)" : "=v"(old2) : "v"((unsigned)(size_t)s + (a2 >> 1) * 4u), "v"(m2), "v"(v2) : "memory");
         if (((old2 >> sh) & 0xFFFFu) != exp2) nbad++;
         __syncthreads();
+        // returning add of 1: consecutive slots in lane order (the stable partition step of lz_hc_build)
+        for (unsigned i = lane; i < 256; i += 64) s[i] = 1000u * i;
+        __syncthreads();
+        unsigned exp3 = 1000u * a;
+        for (unsigned l = 0; l < 64; l++) { const unsigned al = __shfl(a, l); if (l < lane && al == a) exp3++; }
+        unsigned old3;
+        asm volatile("ds_add_rtn_u32 %0, %1, %2\n s_waitcnt lgkmcnt(0)" : "=v"(old3) : "v"((unsigned)(size_t)s + off), "v"(1u) : "memory");
+        if (old3 != exp3) nbad++;
+        __syncthreads();
     }
     atomicAdd(bad, nbad);
 }
@@ -50,6 +59,6 @@ int main()
     (void)hipMemcpy(d, h, trials * 64 * 4, hipMemcpyHostToDevice); (void)hipMemset(bad, 0, 4);
     hipLaunchKernelGGL(k, dim3(64), dim3(64), 0, 0, d, bad, trials);
     (void)hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost);
-    printf("lds atomic lane-order violations: %u (of %d trials x 2 ops x 64 workgroups)\n", hb, trials);
+    printf("lds atomic lane-order violations: %u (of %d trials x 3 ops x 64 workgroups)\n", hb, trials);
     return hb != 0;
 }

@@ -53,18 +53,17 @@ def test_emulated_hashchain_vs_oracle(level):
         assert emul_compress(data, level, seed=len(name) + level) == util.oracle_compress(data, level), (name, level)
 
 
-def test_emulated_hashchain_epoch_wrap():
-    """The head table is never cleared between blocks: entries carry a 10-bit epoch and the table is
-    re-zeroed when it wraps (lz_hc_begin).  Drive one slot across the wrap with unrelated blocks."""
-    emu = util.emulator()
-    emu.emul_hc_get_epoch.restype = ctypes.c_uint
-    emu.emul_hc_set_epoch(1020)
-    seen = []
-    for i in range(6):
-        data = util.datagen(70000 + 977 * i, 0.5, 0.0, 100 + i)
-        assert emul_compress(data, 14, seed=i) == util.oracle_compress(data, 14), i
-        seen.append(emu.emul_hc_get_epoch())
-    assert seen == [1021, 1022, 1023, 1, 2, 3]
+def test_emulated_hashchain_slot_reuse():
+    """The per-wave global slot of the hashChain levels (bins, links, saved head tables) is never cleared between
+    blocks: nothing an earlier block left there may matter.  Unrelated blocks through one slot, among them one of
+    more than 2^18 positions (two segments: the head tables travel through the slot) and runs (the scalar replay)."""
+    cases = [util.datagen(70000 + 977 * i, 0.5, 0.0, 100 + i) for i in range(3)]
+    cases.append(b"\0" * 5000 + util.datagen(3000, 0.3, 0.0, 7) + b"ab" * 3000 + b"\0" * 700)
+    cases.append(util.datagen(300000, 0.6, 0.0, 9)[:150000] + util.datagen(150000, 0.6, 0.0, 9))   # repeats across the segment border
+    cases.append(util.datagen(64, 0.5, 0.0, 3))
+    for i, data in enumerate(cases):
+        for level in (14, 16):
+            assert emul_compress(data, level, seed=i) == util.oracle_compress(data, level), (i, level)
 
 
 def test_emulated_kernel_schedule_independent():

@@ -137,14 +137,14 @@ def test_known_answers_p50_64m_device_path(L, key):
     assert torch.equal(dst.view(-1, stride)[sel], dst2.view(-1, stride)[sel])
 
 
-def test_hashchain_epoch_wrap_on_device(L):
-    """The hashChain head tables are never cleared between blocks: their slots carry a 10-bit epoch and a table is
-    re-zeroed after 1023 blocks (lz_hc_begin).  One launch over enough small blocks makes every resident wave go
-    through the wrap at least once; a sample of blocks before, around and after it must still be bit-exact."""
+def test_hashchain_many_small_blocks_reuse_slots(L):
+    """The hashChain waves keep bins, links and the chain array in a per-wave global slot that is never cleared, and borrow
+    their LDS region from a pool of the workgroup.  One launch over several hundred small blocks per resident wave: a
+    sample of blocks from start to end must be bit-exact."""
     import torch
     from lizard_amd import api
     bs = 192
-    nb = int(L.LizardGPU_residentWaves()) * 1150
+    nb = int(L.LizardGPU_residentWaves()) * 300
     rnd = np.random.RandomState(5)
     words = rnd.randint(0, 256, size=(64, 24), dtype=np.uint8)           # 64 phrases of 24 bytes: lots of matches per block
     host = words[rnd.randint(0, 64, size=nb * (bs // 24))].reshape(-1)[:nb * bs].copy()
