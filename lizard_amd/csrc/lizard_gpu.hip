@@ -64,7 +64,9 @@ struct LzBatch {
 #endif
 #define LZ_WAVES_FASTLDS      13             // all tables in LDS (blocks above 4 MiB)
 #define LZ_WAVES_FASTLDS_HUF  11
+#ifndef LZ_MAX_WAVES
 #define LZ_MAX_WAVES          16             // scratch / table slots per CU
+#endif
 
 // NLDS of the W waves keep their hash table in LDS (form LDSKIND), the others in the wave's global-memory slot.
 template <int PARSER, int HASHLOG, int AUX, bool HUF, int W, int WSWORDS, int NLDS = (HASHLOG > 14 ? 0 : W), u32 LDSKIND = LZ_TABKIND_LDS, int POOL = 0>

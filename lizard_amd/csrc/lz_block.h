@@ -700,6 +700,7 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
         const u32 row = (level >= 30u ? level - 21u : level) - 13u;                  // lizard_common.h:240-244, :264-268
         lz_hc_begin(hc, tableMem, maxBlock, row == 4u ? 256u : 2u << row);
         lz_hc_build<AUX>(src, n, hc, *hcPool, st);
+        lz_hc_hits(src, n, hc);
     }
     else if constexpr (kWide) lz_tab_fresh<HASHLOG>(tabw);
     else if constexpr (PARSER == LZ_PARSER_FAST) {

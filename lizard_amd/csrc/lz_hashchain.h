@@ -53,18 +53,21 @@
 //   links  u32[2^18]  (link << 16 | position in its 2^14 window), in bin order
 //   wins   u32[17*64] cursor of every bin at every window boundary
 //   heads  u32[2^18]  head tables between segments (blocks above 2^18 positions only)
-//   prev   u16[maxBlock]
+//   hits   u64[maxBlock/64 + 64]  one bit per position: "a search here finds a match" (lz_hc_hits)
+//   prev   u16[maxBlock]   distance to the previous head of the position's bucket (0 = none): the chain
 #define LZ_HC_BINS_BYTES  (4u << LZ_HC_SEGLOG)
 #define LZ_HC_LINKS_BYTES (4u << LZ_HC_SEGLOG)
 #define LZ_HC_WINS_BYTES  8192u
 #define LZ_HC_HEADS_BYTES(maxBlock) ((size_t)(maxBlock) > (1u << LZ_HC_SEGLOG) ? (size_t)(4u << LZ_HC_HASHLOG) : 0u)
-#define LZ_HC_SLOT_BYTES(maxBlock) ((size_t)LZ_HC_BINS_BYTES + LZ_HC_LINKS_BYTES + LZ_HC_WINS_BYTES + LZ_HC_HEADS_BYTES(maxBlock) + 2u * (size_t)(maxBlock) + 128u)
+#define LZ_HC_HITS_BYTES(maxBlock) ((((size_t)(maxBlock) + 63u) / 64u + 64u) * 8u)
+#define LZ_HC_SLOT_BYTES(maxBlock) ((size_t)LZ_HC_BINS_BYTES + LZ_HC_LINKS_BYTES + LZ_HC_WINS_BYTES + LZ_HC_HEADS_BYTES(maxBlock) + LZ_HC_HITS_BYTES(maxBlock) + 2u * (size_t)(maxBlock) + 128u)
 
 struct LzHc {
     u32* bins;          // global
     u32* links;         // global
     u32* wins;          // global
     u32* heads;         // global (multi-segment blocks)
+    u64* hits;          // global: bit p = a search at p finds a match
     u16* prev;          // global: per block position, distance to the previous head of its bucket (0 = none)
     u32  searchNum;     // uniform
 };
@@ -84,6 +87,7 @@ LZ_DEV void lz_hc_begin(LzHc& hc, void* slotMem, u32 maxBlock, u32 searchNum)
     hc.links = (u32*)m;  m += LZ_HC_LINKS_BYTES;
     hc.wins = (u32*)m;   m += LZ_HC_WINS_BYTES;
     hc.heads = (u32*)m;  m += LZ_HC_HEADS_BYTES(maxBlock);
+    hc.hits = (u64*)m;   m += LZ_HC_HITS_BYTES(maxBlock);
     hc.prev = (u16*)m;
     hc.searchNum = searchNum;
 }
@@ -340,6 +344,55 @@ LZ_DEV void lz_hc_build(const u8* src, u32 n, const LzHc& hc, const LzHufPool& p
     lz_pool_release(pool, poolSlot);
 }
 
+// The parse's outer loop (hashchain.h:204-206) advances position by position until Lizard_InsertAndFindBestMatch finds
+// anything at all: "one of the first searchNum chain candidates of p lies inside the window, at least MIN_OFFSET back, and
+// agrees with p in 4 bytes" (:66-73 make ml >= 4 > 0 exactly then).  That is a function of p alone once the chain exists, so it
+// is evaluated for all positions of the block ahead of the parse, LZ_HC_BULK x 64 positions at a time with their memory trips
+// side by side, into one bit per position; the outer loop becomes a bit scan.  (The parse used to walk the chains of 64
+// positions per round on its own serial path: three dependent memory trips per sequence.)
+#ifndef LZ_HC_BULK
+#define LZ_HC_BULK 8u
+#endif
+LZ_DEV void lz_hc_hits(const u8* src, u32 n, const LzHc& hc)
+{
+    const u32 lane = lz_lane();
+    const u32 nIns = n >= 8u ? n - 7u : 0u;                      // positions that have a chain link (lz_hc_build)
+    for (u32 base = 0; base < nIns; base += 64u * LZ_HC_BULK) {
+        u32 p[LZ_HC_BULK], m[LZ_HC_BULK], d[LZ_HC_BULK], f4[LZ_HC_BULK];
+        bool walking[LZ_HC_BULK], hit[LZ_HC_BULK];
+        #pragma unroll
+        for (u32 k = 0; k < LZ_HC_BULK; k++) {
+            p[k] = base + k * 64u + lane;
+            walking[k] = p[k] < nIns; hit[k] = false;
+            m[k] = walking[k] ? p[k] : 0u;
+            f4[k] = lz_ld32(src + m[k]); d[k] = hc.prev[m[k]];
+        }
+        for (u32 a = 0; a < hc.searchNum; a++) {
+            bool any = false;
+            #pragma unroll
+            for (u32 k = 0; k < LZ_HC_BULK; k++) {
+                walking[k] = walking[k] && d[k] != 0u && p[k] - (m[k] - d[k]) <= LZ_MAX_DIST_LZ4;
+                any = any || walking[k];
+                m[k] = walking[k] ? m[k] - d[k] : m[k];
+            }
+            if (!lz_ballot(any)) break;
+            u32 c4[LZ_HC_BULK];
+            #pragma unroll
+            for (u32 k = 0; k < LZ_HC_BULK; k++) { c4[k] = lz_ld32(src + m[k]); d[k] = hc.prev[m[k]]; }
+            #pragma unroll
+            for (u32 k = 0; k < LZ_HC_BULK; k++)
+                if (walking[k] && p[k] - m[k] >= LZ_MIN_OFFSET && c4[k] == f4[k]) { hit[k] = true; walking[k] = false; }
+        }
+        u64 mine = 0;
+        #pragma unroll
+        for (u32 k = 0; k < LZ_HC_BULK; k++) {
+            const u64 w = lz_ballot(hit[k]); mine = lane == k ? w : mine;
+        }
+        if (lane < LZ_HC_BULK && base + lane * 64u < nIns) hc.hits[(base >> 6) + lane] = mine;
+    }
+    lz_wave_sync();
+}
+
 // One search of the chain that starts at X (uniform).  wider == false: Lizard_InsertAndFindBestMatch
 // (longest = 0 on entry, iLow unused); wider == true: Lizard_InsertAndGetWiderMatch with backward
 // extension down to iLow.  Returns the new longest; ref/start change only when it grew.
@@ -436,32 +489,18 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const Lz
     const int mflimit = (int)E - (int)LZ_MFLIMIT, matchlimit = (int)E - (int)LZ_LASTLITERALS;
     int ml = 0, ml2 = 0, ml3 = 0, ml0 = 0, start0 = 0;
     u32 ref = 0, ref2 = 0, ref3 = 0, ref0 = 0, start2 = 0, start3 = 0, dummy = 0;
+    u32 bmBase = 0xFFFF0000u;                                    // first word of the hit bits held in bm (none yet)
+    u64 bm = 0;
     for (;;) {
-        // ---------------- :204-206: first position with any match, 64 positions per round ----------------
+        // ---------------- :204-206: first position with any match: a scan of the hit bits ----------------
         for (;;) {
             if (ip >= mflimit) goto tail;
-            const u32 p = (u32)ip + lane;
-            const bool valid = (int)p < mflimit;
-            // Wave-uniform loop over chain steps.  A step costs one round trip: the candidate's 4 bytes and
-            // its own link are fetched together.  Lanes above the lowest lane that already has a match stop
-            // walking — the reference never reaches their positions.
-            bool hit = false, walking = valid;
-            const u32 first4 = lz_ld32(src + (valid ? p : S));
-            u32 m = valid ? p : S;
-            u32 d = hc.prev[m];
-            for (u32 a = 0; a < hc.searchNum; a++) {
-                walking = walking && d != 0u && p - (m - d) <= LZ_MAX_DIST_LZ4;
-                if (!lz_ballot(walking)) break;
-                m = walking ? m - d : m;
-                const u32 c4 = lz_ld32(src + m);
-                d = hc.prev[m];
-                if (walking && p - m >= LZ_MIN_OFFSET && c4 == first4) { hit = true; walking = false; }
-                const u64 hm = lz_ballot(hit);
-                if (hm) walking = walking && lane < lz_ctz64(hm);
-            }
-            const u64 okMask = lz_ballot(hit);
-            if (okMask) { ip += (int)lz_ctz64(okMask); break; }
-            ip += (int)lz_popc64(lz_ballot(valid));
+            const u32 wi = (u32)ip >> 6;
+            if (wi - bmBase >= 64u) { bmBase = wi; bm = hc.hits[bmBase + lane]; }       // 4096 positions of bits, one word per lane
+            const u32 li = wi - bmBase;
+            const u64 w = (((u64)lz_readlane((u32)(bm >> 32), li) << 32) | lz_readlane((u32)bm, li)) >> ((u32)ip & 63u);
+            if (w) { ip += (int)lz_ctz64(w); if (ip >= mflimit) goto tail; break; }
+            ip = (int)((wi + 1u) << 6);
         }
         LZ_PROF(st, 0);
         ml = (int)lz_hc_search(src, nBlock, hc, (u32)ip, (u32)ip, (u32)matchlimit, 0u, false, ref, dummy, st);
