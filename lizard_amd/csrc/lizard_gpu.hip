@@ -56,10 +56,10 @@ struct LzBatch {
 #ifndef LZ_NLDS_FAST_HUF
 #define LZ_NLDS_FAST_HUF   11
 #endif
-#ifndef LZ_HUF_POOL
 #ifndef LZ_HC_POOL
 #define LZ_HC_POOL         3              // chain-build regions (32.3 KiB each) shared by the waves of a hashChain workgroup
 #endif
+#ifndef LZ_HUF_POOL
 #define LZ_HUF_POOL        5              // Huffman workspaces shared by the 16 waves of a level-30 workgroup (0 = one each)
 #endif
 #define LZ_WAVES_FASTLDS      13             // all tables in LDS (blocks above 4 MiB)
