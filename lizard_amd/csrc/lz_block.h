@@ -259,11 +259,14 @@ LZ_DEV void lz_encode_lz4(const u8* src, u32 S, const LzStreams& st, u8* litOut,
 {
     const u32 lane = lz_lane();
     u32 srcPos = S, outPos = 0;                                   // uniform carries
+    // the next step's sequences are requested one step ahead (clamped, unconditional): a step is a chain of scans and stores
+    u64 qNext = st.nseq ? lz_ldq_s(&st.seq[lane < st.nseq ? lane : st.nseq - 1u]) : 0ull;
     for (u32 base = 0; base < st.nseq; base += 64u) {
         const u32 cnt = st.nseq - base < 64u ? st.nseq - base : 64u;
         u32 L = 0, mlc = 0, off = 0, R = 0, adv = 0;
+        const u64 q = qNext;
+        { const u32 nx = base + 64u + lane; qNext = lz_ldq_s(&st.seq[nx < st.nseq ? nx : st.nseq - 1u]); }
         if (lane < cnt) {
-            const u64 q = lz_ldq_s(&st.seq[base + lane]);
             L = (u32)q & 0x3FFFFu; mlc = (u32)(q >> 18) & 0x3FFFFu; off = (u32)(q >> 36);
             R = lz_lz4_record_bytes(L, mlc); adv = L + mlc + 4u;
         }

@@ -346,16 +346,20 @@ LZ_DEV void lz_huf_pack_segment(const u8* src, u32 a, u32 b, u8* out, u32 nbytes
     u32 cur = 0;            // uniform: bits pending in stage[0] (< 32)
     u32 wordsOut = 0;       // uniform: dwords already stored to `out`
     u32 remaining = b - a;  // uniform: symbols not yet appended; next to append is src[a + remaining - 1]
+    // my dword of a full step, requested one step ahead (the step itself is a chain of LDS trips: scan, or, store)
+    u32 wNext = (remaining >= 256u) ? lz_ld32(src + a + remaining - 4u - lane * 4u) : 0u;
     while (remaining > 0) {
         // lane takes up to 4 symbols: src[hi-3 .. hi], appended in the order hi, hi-1, hi-2, hi-3
         const u32 take = remaining < 256u ? remaining : 256u;
         const u32 first = lane * 4u;                      // index (in append order) of my first symbol in this step
         u64 acc = 0; u32 len = 0;
+        const u32 wCur = wNext;
+        if (remaining >= 512u) wNext = lz_ld32(src + a + remaining - 256u - 4u - lane * 4u);    // uniform condition
         if (first < take) {
             const u32 cnt = take - first < 4u ? take - first : 4u;
             const u32 hi = a + remaining - 1u - first;
             if (cnt == 4u) {                                  // one dword load, four independent table lookups
-                const u32 w4 = lz_ld32(src + hi - 3u);
+                const u32 w4 = take == 256u ? wCur : lz_ld32(src + hi - 3u);
                 const u32 e0 = ctab[w4 >> 24], e1 = ctab[(w4 >> 16) & 255u], e2 = ctab[(w4 >> 8) & 255u], e3 = ctab[w4 & 255u];
                 acc = (u64)(e0 & 0xFFFu);               len = e0 >> 12;
                 acc |= (u64)(e1 & 0xFFFu) << len;       len += e1 >> 12;
@@ -422,8 +426,20 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
     for (u32 i = lane; i < 256u; i += 64u) count[i] = 0;
     lz_lds_sync();
     {
-        const u32 n4 = n & ~3u;
-        for (u32 i = lane * 4u; i < n4; i += 256u) {
+        const u32 n4 = n & ~3u, n16 = n & ~1023u;
+        for (u32 i = lane * 4u; i < n16; i += 1024u) {             // four loads in flight: a step is one memory trip long
+            u32 w[4];
+            #pragma unroll
+            for (u32 k = 0; k < 4u; k++) w[k] = lz_ld32(stream + i + k * 256u);
+            #pragma unroll
+            for (u32 k = 0; k < 4u; k++) {
+                lz_lds_atomic_add(&count[w[k] & 255u], 1u);
+                lz_lds_atomic_add(&count[(w[k] >> 8) & 255u], 1u);
+                lz_lds_atomic_add(&count[(w[k] >> 16) & 255u], 1u);
+                lz_lds_atomic_add(&count[w[k] >> 24], 1u);
+            }
+        }
+        for (u32 i = n16 + lane * 4u; i < n4; i += 256u) {
             const u32 w = lz_ld32(stream + i);
             lz_lds_atomic_add(&count[w & 255u], 1u);
             lz_lds_atomic_add(&count[(w >> 8) & 255u], 1u);
@@ -606,8 +622,17 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
             for (u32 k = 0; k < 4u; k++) {
                 const u32 a = k * seg, b = (k == 3u) ? n : (k + 1u) * seg;
                 u32 bits = 0;                                  // 4 symbols per lane per step (vector-memory cost is per instruction)
-                const u32 n4 = (b - a) & ~3u;
-                for (u32 i = lane * 4u; i < n4; i += 256u) {
+                const u32 n4 = (b - a) & ~3u, n16 = (b - a) & ~1023u;
+                for (u32 i = lane * 4u; i < n16; i += 1024u) {     // four loads in flight
+                    u32 w[4];
+                    #pragma unroll
+                    for (u32 j = 0; j < 4u; j++) w[j] = lz_ld32(stream + a + i + j * 256u);
+                    #pragma unroll
+                    for (u32 j = 0; j < 4u; j++)
+                        bits += ((u32)ctab[w[j] & 255u] >> 12) + ((u32)ctab[(w[j] >> 8) & 255u] >> 12)
+                              + ((u32)ctab[(w[j] >> 16) & 255u] >> 12) + ((u32)ctab[w[j] >> 24] >> 12);
+                }
+                for (u32 i = n16 + lane * 4u; i < n4; i += 256u) {
                     const u32 w = lz_ld32(stream + a + i);
                     bits += ((u32)ctab[w & 255u] >> 12) + ((u32)ctab[(w >> 8) & 255u] >> 12)
                           + ((u32)ctab[(w >> 16) & 255u] >> 12) + ((u32)ctab[w >> 24] >> 12);

@@ -107,13 +107,15 @@ LZ_DEV void lz_encode_lizv1(const u8* src, u32 S, const LzStreams& st, u8* litOu
 {
     const u32 lane = lz_lane();
     u32 srcPos = S, outPos = 0, fPos = 0, o16Pos = 0, o24Pos = 0;        // uniform carries
+    u64 qNext = st.nseq ? st.seq[lane < st.nseq ? lane : st.nseq - 1u] : 0ull;    // one step ahead, as in lz_encode_lz4
     for (u32 base = 0; base < st.nseq; base += 64u) {
         const u32 cnt = st.nseq - base < 64u ? st.nseq - base : 64u;
         u32 L = 0, ml = 0, off = 0, R = 0, adv = 0, packed = 0, tok = 0, litTok = 0;
         u32 extLw = 0, extLn = 0, extMw = 0, extMn = 0;
         bool longOff = false;
+        const u64 q = qNext;
+        { const u32 nx = base + 64u + lane; qNext = st.seq[nx < st.nseq ? nx : st.nseq - 1u]; }
         if (lane < cnt) {
-            const u64 q = st.seq[base + lane];
             L = (u32)q & 0x3FFFFu; ml = (u32)(q >> 18) & 0x3FFFFu; off = (u32)(q >> 36);
             longOff = off >= LZ_16BIT_OFFSET;
             litTok = L >= 7u ? 7u : L;
