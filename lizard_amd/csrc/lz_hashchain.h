@@ -55,12 +55,13 @@
 //   heads  u32[2^18]  head tables between segments (blocks above 2^18 positions only)
 //   hits   u64[maxBlock/64 + 64]  one bit per position: "a search here finds a match" (lz_hc_hits)
 //   prev   u16[maxBlock]   distance to the previous head of the position's bucket (0 = none): the chain
+//   chain2 u32[maxBlock]   prev | two links at once << 16 (0 = the second is missing or out of every window): what the searches walk
 #define LZ_HC_BINS_BYTES  (4u << LZ_HC_SEGLOG)
 #define LZ_HC_LINKS_BYTES (4u << LZ_HC_SEGLOG)
 #define LZ_HC_WINS_BYTES  8192u
 #define LZ_HC_HEADS_BYTES(maxBlock) ((size_t)(maxBlock) > (1u << LZ_HC_SEGLOG) ? (size_t)(4u << LZ_HC_HASHLOG) : 0u)
 #define LZ_HC_HITS_BYTES(maxBlock) ((((size_t)(maxBlock) + 63u) / 64u + 64u) * 8u)
-#define LZ_HC_SLOT_BYTES(maxBlock) ((size_t)LZ_HC_BINS_BYTES + LZ_HC_LINKS_BYTES + LZ_HC_WINS_BYTES + LZ_HC_HEADS_BYTES(maxBlock) + LZ_HC_HITS_BYTES(maxBlock) + 2u * (size_t)(maxBlock) + 128u)
+#define LZ_HC_SLOT_BYTES(maxBlock) ((size_t)LZ_HC_BINS_BYTES + LZ_HC_LINKS_BYTES + LZ_HC_WINS_BYTES + LZ_HC_HEADS_BYTES(maxBlock) + LZ_HC_HITS_BYTES(maxBlock) + 6u * (size_t)(maxBlock) + 256u)
 
 struct LzHc {
     u32* bins;          // global
@@ -69,6 +70,7 @@ struct LzHc {
     u32* heads;         // global (multi-segment blocks)
     u64* hits;          // global: bit p = a search at p finds a match
     u16* prev;          // global: per block position, distance to the previous head of its bucket (0 = none)
+    u32* chain2;        // global: prev[p] | (prev[p] + prev[p - prev[p]]) << 16 (upper half 0 = no second link inside any window)
     u32  searchNum;     // uniform
 };
 
@@ -88,7 +90,8 @@ LZ_DEV void lz_hc_begin(LzHc& hc, void* slotMem, u32 maxBlock, u32 searchNum)
     hc.wins = (u32*)m;   m += LZ_HC_WINS_BYTES;
     hc.heads = (u32*)m;  m += LZ_HC_HEADS_BYTES(maxBlock);
     hc.hits = (u64*)m;   m += LZ_HC_HITS_BYTES(maxBlock);
-    hc.prev = (u16*)m;
+    hc.prev = (u16*)m;   m += 2u * (size_t)maxBlock + 128u;
+    hc.chain2 = (u32*)m;
     hc.searchNum = searchNum;
 }
 
@@ -358,7 +361,7 @@ LZ_DEV void lz_hc_hits(const u8* src, u32 n, const LzHc& hc)
     const u32 lane = lz_lane();
     const u32 nIns = n >= 8u ? n - 7u : 0u;                      // positions that have a chain link (lz_hc_build)
     for (u32 base = 0; base < nIns; base += 64u * LZ_HC_BULK) {
-        u32 p[LZ_HC_BULK], m[LZ_HC_BULK], d[LZ_HC_BULK], f4[LZ_HC_BULK];
+        u32 p[LZ_HC_BULK], m[LZ_HC_BULK], d[LZ_HC_BULK], f4[LZ_HC_BULK], two[LZ_HC_BULK];
         bool walking[LZ_HC_BULK], hit[LZ_HC_BULK];
         #pragma unroll
         for (u32 k = 0; k < LZ_HC_BULK; k++) {
@@ -366,6 +369,7 @@ LZ_DEV void lz_hc_hits(const u8* src, u32 n, const LzHc& hc)
             walking[k] = p[k] < nIns; hit[k] = false;
             m[k] = walking[k] ? p[k] : 0u;
             f4[k] = lz_ld32(src + m[k]); d[k] = hc.prev[m[k]];
+            two[k] = d[k];                                       // becomes prev | two links << 16
         }
         for (u32 a = 0; a < hc.searchNum; a++) {
             bool any = false;
@@ -379,6 +383,13 @@ LZ_DEV void lz_hc_hits(const u8* src, u32 n, const LzHc& hc)
             u32 c4[LZ_HC_BULK];
             #pragma unroll
             for (u32 k = 0; k < LZ_HC_BULK; k++) { c4[k] = lz_ld32(src + m[k]); d[k] = hc.prev[m[k]]; }
+            if (a == 0u) {                                       // the second link, for lz_hc_search's two-at-a-time walk
+                #pragma unroll
+                for (u32 k = 0; k < LZ_HC_BULK; k++) {
+                    const u32 sum = (p[k] - m[k]) + d[k];
+                    if (walking[k] && d[k] != 0u && sum <= LZ_MAX_DIST_LZ4) two[k] |= sum << 16;
+                }
+            }
             #pragma unroll
             for (u32 k = 0; k < LZ_HC_BULK; k++)
                 if (walking[k] && p[k] - m[k] >= LZ_MIN_OFFSET && c4[k] == f4[k]) { hit[k] = true; walking[k] = false; }
@@ -387,6 +398,7 @@ LZ_DEV void lz_hc_hits(const u8* src, u32 n, const LzHc& hc)
         #pragma unroll
         for (u32 k = 0; k < LZ_HC_BULK; k++) {
             const u64 w = lz_ballot(hit[k]); mine = lane == k ? w : mine;
+            if (p[k] < nIns) hc.chain2[p[k]] = two[k];
         }
         if (lane < LZ_HC_BULK && base + lane * 64u < nIns) hc.hits[(base >> 6) + lane] = mine;
     }
@@ -411,13 +423,21 @@ LZ_DEV u32 lz_hc_search(const u8* src, u32 nBlock, const LzHc& hc, u32 X, u32 iL
     while (more && left) {
         const u32 batch = left < 64u ? left : 64u;
         u32 cand = 0, cnt = 0;
-        for (u32 j = 0; j < batch; j++) {                        // the walk itself is serial: one link per step
-            const u32 d = lz_uniform((u32)hc.prev[m]);
-            if (!d) { more = false; break; }
-            m -= d;
-            if (X - m > LZ_MAX_DIST_LZ4) { more = false; break; }
-            if (lane == j) cand = m;
+        for (u32 j = 0; j < batch; j += 2u) {                    // the walk is serial; one word brings two links
+            const u32 w2 = lz_uniform(hc.chain2[m]);
+            const u32 d1 = w2 & 0xFFFFu, d2 = w2 >> 16;
+            if (!d1) { more = false; break; }
+            const u32 m1 = m - d1;
+            if (X - m1 > LZ_MAX_DIST_LZ4) { more = false; break; }
+            if (lane == j) cand = m1;
             cnt++;
+            if (j + 1u >= batch) { m = m1; break; }
+            if (!d2) { more = false; break; }                    // no second link, or farther than any window reaches
+            const u32 m2 = m - d2;
+            if (X - m2 > LZ_MAX_DIST_LZ4) { more = false; break; }
+            if (lane == j + 1u) cand = m2;
+            cnt++;
+            m = m2;
         }
         left -= cnt;
         LZ_PROF(st, 8);                                          // (instrumented build) chain walk
