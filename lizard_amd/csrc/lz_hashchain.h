@@ -422,29 +422,30 @@ LZ_DEV u32 lz_hc_search(const u8* src, u32 nBlock, const LzHc& hc, u32 X, u32 iL
     bool more = true;
     while (more && left) {
         const u32 batch = left < 64u ? left : 64u;
-        u32 cand = 0, cnt = 0;
+        u32 cand = 0, cnt = 0, c4 = 0;                           // c4: the candidate's 4 test bytes, requested as soon as it is known
         for (u32 j = 0; j < batch; j += 2u) {                    // the walk is serial; one word brings two links
             const u32 w2 = lz_uniform(hc.chain2[m]);
             const u32 d1 = w2 & 0xFFFFu, d2 = w2 >> 16;
             if (!d1) { more = false; break; }
             const u32 m1 = m - d1;
             if (X - m1 > LZ_MAX_DIST_LZ4) { more = false; break; }
-            if (lane == j) cand = m1;
+            if (lane == j) { cand = m1; c4 = lz_ld32(src + m1); }
             cnt++;
             if (j + 1u >= batch) { m = m1; break; }
             if (!d2) { more = false; break; }                    // no second link, or farther than any window reaches
             const u32 m2 = m - d2;
             if (X - m2 > LZ_MAX_DIST_LZ4) { more = false; break; }
-            if (lane == j + 1u) cand = m2;
+            if (lane == j + 1u) { cand = m2; c4 = lz_ld32(src + m2); }
             cnt++;
             m = m2;
         }
         left -= cnt;
         LZ_PROF(st, 8);                                          // (instrumented build) chain walk
-        // The 4-byte test first: few candidates pass it, and what they read next lies in the line the test just fetched.
+        // The 4-byte test first (its bytes were requested during the walk): few candidates pass it, and what they read next
+        // lies in the line the test fetched.
         u32 mlt = 0, bk = 0;
         bool open = false;                                       // my comparison needs the wave-wide helpers
-        const bool ok = lane < cnt && X - cand >= LZ_MIN_OFFSET && lz_ld32(src + cand) == first4;
+        const bool ok = lane < cnt && X - cand >= LZ_MIN_OFFSET && c4 == first4;                 // :73 / :146
         if (ok) {
             u32 f = 4u;
             bool eq = true;
