@@ -57,7 +57,7 @@ struct LzBatch {
 #define LZ_NLDS_FAST_HUF   11
 #endif
 #ifndef LZ_HC_POOL
-#define LZ_HC_POOL         3              // chain-build regions (32.3 KiB each) shared by the waves of a hashChain workgroup
+#define LZ_HC_POOL         3              // chain-build regions (32.3 KiB each) shared by the waves of a hashChain workgroup (one more without Huffman)
 #endif
 #ifndef LZ_HUF_POOL
 #define LZ_HUF_POOL        5              // Huffman workspaces shared by the 16 waves of a level-30 workgroup (0 = one each)
@@ -85,7 +85,7 @@ __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
     __shared__ u32 hufPool[POOL ? POOL : 1][POOL ? LZ_HUF_WS_WORDS : 1];
     __shared__ u32 hufPoolMask;
     // hashChain: the chain build of a block borrows one of HCPOOL 32 KiB regions (lz_hc_build)
-    constexpr int HCPOOL = PARSER == LZ_PARSER_HASHCHAIN ? LZ_HC_POOL : 0;
+    constexpr int HCPOOL = PARSER == LZ_PARSER_HASHCHAIN ? (HUF ? LZ_HC_POOL : LZ_HC_POOL + 1) : 0;   // the Huffman workspaces take a region's worth of LDS
     static_assert(!(POOL != 0 && HCPOOL != 0), "one pool mask per workgroup");
     __shared__ u32 hcPoolMem[HCPOOL ? HCPOOL : 1][HCPOOL ? LZ_HC_REGION_WORDS : 1];
     if constexpr (POOL != 0 || HCPOOL != 0) { if (threadIdx.x == 0) hufPoolMask = 0; __syncthreads(); }
