@@ -364,7 +364,7 @@ def main():
             cap = nbe * api.Lizard_compressBound(bs)
             outbuf = np.empty(cap, dtype=np.uint8)
             e2e = {"sample": f"first {nbe} blocks x {bs} B of the headline workload, LizardGPU_compressBlocks_host_packed, "
-                             "512 MiB chunks, pinned double-buffered staging, device-side compaction, one D2H per chunk",
+                             "256 MiB chunks, three in flight (issuing + draining host threads, pinned staging), device-side compaction, one D2H per chunk",
                    "unit": "MB/s"}
             for name, t in (("pageable_src", host), ("pinned_src", host.pin_memory())):
                 best = None

@@ -129,9 +129,10 @@ int LizardGPU_compressBlocks_device(const void* d_src, size_t nBlocks, size_t bl
                                     int level, void* stream);
 
 /* Same for HOST-resident buffers (dst slot i at dst + i*dstStride, cSizes[i] bytes valid).  Synchronous.
- * Pipelined in chunks of whole blocks (512 MiB of input, LIZARDGPU_CHUNK_MB overrides): pinned double-buffered
- * staging, H2D, kernels, device-side compaction of the valid bytes, ONE D2H per chunk — copies of one chunk overlap
- * the kernels of the next.  A src that is already pinned (hipHostMalloc / hipHostRegister) is read by DMA directly.
+ * Pipelined in chunks of whole blocks (256 MiB of input, LIZARDGPU_CHUNK_MB overrides), three chunks in flight: pinned
+ * staging, H2D, kernels, device-side compaction of the valid bytes, ONE D2H per chunk.  The calling thread stages and issues,
+ * a second host thread (alive for the duration of the call) drains: uploads, kernels, downloads and the host copies of
+ * different chunks run side by side.  A src that is already pinned (hipHostMalloc / hipHostRegister) is read by DMA directly.
  * _host_packed writes the compressed blocks back to back instead: block i at dst + offsets[i], cSizes[i] bytes,
  * offsets[nBlocks] = total (offsets / cSizes may be NULL); -LIZARDGPU_ERR_ARG if dstCapacity is too small. */
 int LizardGPU_compressBlocks_host(const void* src, size_t nBlocks, size_t blockSize, size_t lastBlockSize,

@@ -246,9 +246,10 @@ __global__ __launch_bounds__(64) void lz_datagen_kernel(u8* dst, u64 nBlocks, u6
 // ------------------------------------------------------------------------------------------------
 // One stage of the host-buffer pipeline: pinned staging on the host side, input / slot / packed buffers on the
 // device side, its own stream.  Two stages alternate so that the copies of one chunk overlap the kernels of the other.
+#define LZ_STAGES 3                                         // chunks in flight in the host-buffer pipeline
 struct Stage {
     hipStream_t stream = nullptr;
-    hipEvent_t  k0 = nullptr, k1 = nullptr, meta = nullptr, done = nullptr;
+    hipEvent_t  k0 = nullptr, k1 = nullptr, meta = nullptr, done = nullptr, up = nullptr;   // up: the chunk's input is on the device
     u8*  h_in = nullptr;     size_t h_in_cap = 0;        // pinned
     u8*  h_out = nullptr;    size_t h_out_cap = 0;       // pinned
     u32* h_sizes = nullptr;  u64* h_offsets = nullptr;   size_t h_meta_cap = 0;   // pinned, nBlocks (+1)
@@ -272,7 +273,7 @@ struct Ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool  timed = false;
     float hostKernelMs = -1.0f; // sum over the chunks of the last host-buffer call (< 0: last call was a device call)
-    Stage stage[2];
+    Stage stage[LZ_STAGES];
     pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
 };
 
@@ -357,6 +358,7 @@ int ctx_init(Ctx& c)
         LZ_HIP(hipEventCreate(&s.k0)); LZ_HIP(hipEventCreate(&s.k1));
         LZ_HIP(hipEventCreateWithFlags(&s.meta, hipEventDisableTiming));
         LZ_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        LZ_HIP(hipEventCreateWithFlags(&s.up, hipEventDisableTiming));
     }
     c.ready = true;
     return 0;
@@ -396,6 +398,7 @@ void ctx_release(Ctx& c)
         if (s.d_packed) (void)hipFree(s.d_packed);
         if (s.d_sizes) (void)hipFree(s.d_sizes);
         if (s.d_offsets) (void)hipFree(s.d_offsets);
+        if (s.up) (void)hipEventDestroy(s.up);
         if (s.k0) (void)hipEventDestroy(s.k0);
         if (s.k1) (void)hipEventDestroy(s.k1);
         if (s.meta) (void)hipEventDestroy(s.meta);
@@ -574,7 +577,7 @@ size_t chunk_bytes()
     if (!g_chunk_bytes) {
         const char* e = getenv("LIZARDGPU_CHUNK_MB");
         size_t mb = e ? (size_t)strtoul(e, nullptr, 10) : 0;
-        if (mb < 1 || mb > 65536) mb = 512;
+        if (mb < 1 || mb > 65536) mb = 256;                  // measured on a 4 GiB job: 256 MiB 37 GB/s, 512 MiB 26, 1 GiB 23 (fill and drain of the pipeline)
         g_chunk_bytes = mb << 20;
     }
     return g_chunk_bytes;
@@ -584,7 +587,7 @@ size_t chunk_bytes()
 // Input is cut into chunks of whole blocks.  Per chunk, on its stage's stream: host -> pinned staging (skipped when
 // the caller's buffer is itself pinned) -> H2D -> block kernels -> exclusive scan of the record sizes -> compaction
 // of the valid bytes into one packed buffer -> D2H of sizes/offsets, then of exactly the packed bytes.  The host
-// then hands each chunk's result to `sink`.  While the GPU works on chunk c the host stages chunk c+1 and drains c-1.
+// then hands each chunk's result to `sink` (run_host_job_inner: an issuing and a draining thread, LZ_STAGES chunks in flight).
 struct HostJob {
     const u8* src; size_t nBlocks, blockSize, lastBlockSize; int level;
     int mode;                                  // LZ_PACK_PAYLOAD or LZ_PACK_FRAME (lz_pack.h)
@@ -596,7 +599,7 @@ struct HostJob {
 
 struct ChunkState { size_t first = 0, nb = 0, inBytes = 0, packedBytes = 0; bool active = false; };
 
-int stage_issue(Ctx& c, Stage& s, const HostJob& j, ChunkState& ch, bool srcPinned)
+int stage_issue(Ctx& c, Stage& s, const HostJob& j, ChunkState& ch, bool srcPinned, hipEvent_t prevUp)
 {
     const size_t slot = ((size_t)LIZARD_COMPRESSBOUND((int)j.blockSize) + 63) & ~(size_t)63;
     const size_t last = (ch.first + ch.nb == j.nBlocks) ? j.lastBlockSize : j.blockSize;
@@ -606,6 +609,7 @@ int stage_issue(Ctx& c, Stage& s, const HostJob& j, ChunkState& ch, bool srcPinn
     if ((rc = ensure_dev(&s.d_in, &s.d_in_cap, ch.inBytes + 64))) return rc;
     if ((rc = ensure_dev(&s.d_slots, &s.d_slots_cap, ch.nb * slot))) return rc;
     if ((rc = ensure_dev(&s.d_packed, &s.d_packed_cap, packedCap))) return rc;
+    if ((rc = ensure_pinned(&s.h_out, &s.h_out_cap, packedCap + 64))) return rc;    // worst case once: a buffer that follows the chunks' sizes is re-pinned again and again
     if (s.d_meta_cap < ch.nb + 1) {
         if (s.d_sizes) { LZ_HIP(hipFree(s.d_sizes)); s.d_sizes = nullptr; }
         if (s.d_offsets) { LZ_HIP(hipFree(s.d_offsets)); s.d_offsets = nullptr; }
@@ -628,7 +632,10 @@ int stage_issue(Ctx& c, Stage& s, const HostJob& j, ChunkState& ch, bool srcPinn
         par_memcpy(s.h_in, from, ch.inBytes);
         from = s.h_in;
     }
+    // uploads run one after the other (an upload that shares the link with the next chunk's finishes late, and its kernels with it)
+    if (prevUp) LZ_HIP(hipStreamWaitEvent(s.stream, prevUp, 0));
     LZ_HIP(hipMemcpyAsync(s.d_in, from, ch.inBytes, hipMemcpyHostToDevice, s.stream));
+    LZ_HIP(hipEventRecord(s.up, s.stream));
     if ((rc = launch(c, s.d_in, ch.nb, j.blockSize, last, s.d_slots, slot, s.d_sizes, j.level, s.stream, s.k0, s.k1))) return rc;
     lz_pack_launch(s.d_in, s.d_slots, slot, s.d_sizes, s.d_offsets, s.d_packed, (u32)ch.nb, (u32)j.blockSize, (u32)last, j.mode, s.stream);
     LZ_HIP(hipGetLastError());
@@ -663,6 +670,61 @@ int run_host_job(Ctx& c, const HostJob& j)
     }
     return rc;
 }
+// Two threads per job.  The calling thread stages and issues chunk after chunk (host -> pinned, H2D, kernels, compaction,
+// sizes D2H); a drain thread follows it chunk by chunk: waits for the sizes, requests exactly the packed bytes, waits for them
+// and hands them to the sink.  With LZ_STAGES chunks in flight neither side waits for the other's host copies, and the two
+// PCIe directions run side by side.
+struct Pipe {
+    Ctx* c; const HostJob* j;
+    size_t nChunks = 0, perChunk = 0;
+    bool srcPinned = false;
+    ChunkState ch[LZ_STAGES];
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    pthread_cond_t cv = PTHREAD_COND_INITIALIZER;
+    size_t issued = 0, drained = 0;            // chunks issued by the caller / handed to the sink by the drain thread
+    int err = 0;                               // first error of either side
+    char errText[sizeof t_err] = {0};
+    float kernelMs = 0.0f;
+};
+void pipe_fail(Pipe& p, int rc)
+{
+    pthread_mutex_lock(&p.mu);
+    if (!p.err) { p.err = rc; memcpy(p.errText, t_err, sizeof p.errText); }
+    pthread_cond_broadcast(&p.cv);
+    pthread_mutex_unlock(&p.mu);
+}
+int drain_chunk(Pipe& p, size_t i)
+{
+    Stage& s = p.c->stage[i % LZ_STAGES];
+    ChunkState& ch = p.ch[i % LZ_STAGES];
+    int rc;
+    if ((rc = stage_fetch(s, ch))) return rc;
+    LZ_HIP(hipEventSynchronize(s.done));
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, s.k0, s.k1) == hipSuccess) p.kernelMs += ms;
+    ch.active = false;
+    return p.j->sink(p.j->user, ch.first, ch.nb, s.h_out, ch.packedBytes, s.h_offsets, s.h_sizes);
+}
+void* drain_thread(void* a)
+{
+    Pipe& p = *(Pipe*)a;
+    t_err[0] = 0;
+    if (hipSetDevice(p.c->device) != hipSuccess) { snprintf(t_err, sizeof t_err, "hipSetDevice(%d) failed", p.c->device); pipe_fail(p, -LIZARDGPU_ERR_HIP); return nullptr; }
+    for (size_t i = 0; i < p.nChunks; i++) {
+        pthread_mutex_lock(&p.mu);
+        while (p.issued <= i && !p.err) pthread_cond_wait(&p.cv, &p.mu);
+        const bool stop = p.err != 0;
+        pthread_mutex_unlock(&p.mu);
+        if (stop) return nullptr;
+        const int rc = drain_chunk(p, i);
+        if (rc) { pipe_fail(p, rc); return nullptr; }
+        pthread_mutex_lock(&p.mu);
+        p.drained = i + 1;
+        pthread_cond_broadcast(&p.cv);
+        pthread_mutex_unlock(&p.mu);
+    }
+    return nullptr;
+}
 int run_host_job_inner(Ctx& c, const HostJob& j)
 {
     int rc = ctx_init(c);
@@ -671,31 +733,37 @@ int run_host_job_inner(Ctx& c, const HostJob& j)
         snprintf(t_err, sizeof t_err, "bad argument (null pointer, zero size or lastBlockSize > blockSize)");
         return -LIZARDGPU_ERR_ARG;
     }
-    size_t perChunk = chunk_bytes() / j.blockSize;
-    if (perChunk == 0) perChunk = 1;
-    const size_t nChunks = (j.nBlocks + perChunk - 1) / perChunk;
-    const bool srcPinned = is_pinned_host(j.src);
-    ChunkState ch[2];
+    Pipe p;
+    p.c = &c; p.j = &j;
+    p.perChunk = chunk_bytes() / j.blockSize;
+    if (p.perChunk == 0) p.perChunk = 1;
+    p.nChunks = (j.nBlocks + p.perChunk - 1) / p.perChunk;
+    p.srcPinned = is_pinned_host(j.src);
     c.hostKernelMs = 0.0f;
-    // iteration i: drain chunk i-2 (its stage is about to be reused), issue chunk i, fetch chunk i-1
-    for (size_t i = 0; i < nChunks + 2; i++) {
-        Stage& s = c.stage[i & 1];
-        ChunkState& cur = ch[i & 1];
-        if (cur.active) {
-            LZ_HIP(hipEventSynchronize(s.done));
-            float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, s.k0, s.k1) == hipSuccess) c.hostKernelMs += ms;
-            cur.active = false;
-            if ((rc = j.sink(j.user, cur.first, cur.nb, s.h_out, cur.packedBytes, s.h_offsets, s.h_sizes))) return rc;
+    pthread_t th;
+    const bool threaded = p.nChunks > 1 && pthread_create(&th, nullptr, drain_thread, &p) == 0;
+    for (size_t i = 0; i < p.nChunks; i++) {
+        if (threaded) {                                          // the stage of chunk i is free once chunk i - LZ_STAGES is drained
+            pthread_mutex_lock(&p.mu);
+            while (i >= p.drained + LZ_STAGES && !p.err) pthread_cond_wait(&p.cv, &p.mu);
+            const bool stop = p.err != 0;
+            pthread_mutex_unlock(&p.mu);
+            if (stop) break;
         }
-        if (i < nChunks) {
-            cur.first = i * perChunk;
-            cur.nb = j.nBlocks - cur.first < perChunk ? j.nBlocks - cur.first : perChunk;
-            if ((rc = stage_issue(c, s, j, cur, srcPinned))) return rc;
-        }
-        if (i >= 1 && ch[(i - 1) & 1].active && i - 1 < nChunks)
-            if ((rc = stage_fetch(c.stage[(i - 1) & 1], ch[(i - 1) & 1]))) return rc;
+        ChunkState& cur = p.ch[i % LZ_STAGES];
+        cur.first = i * p.perChunk;
+        cur.nb = j.nBlocks - cur.first < p.perChunk ? j.nBlocks - cur.first : p.perChunk;
+        if ((rc = stage_issue(c, c.stage[i % LZ_STAGES], j, cur, p.srcPinned, i ? c.stage[(i - 1) % LZ_STAGES].up : nullptr))) { pipe_fail(p, rc); break; }
+        if (threaded) {
+            pthread_mutex_lock(&p.mu);
+            p.issued = i + 1;
+            pthread_cond_broadcast(&p.cv);
+            pthread_mutex_unlock(&p.mu);
+        } else if ((rc = drain_chunk(p, i))) { pipe_fail(p, rc); break; }
     }
+    if (threaded) pthread_join(th, nullptr);
+    c.hostKernelMs = p.kernelMs;
+    if (p.err) { memcpy(t_err, p.errText, sizeof p.errText); return p.err; }
     return 0;
 }
 
