@@ -548,11 +548,14 @@ int launch_decompress(Ctx& c, const void* d_src, const u64* d_offsets, size_t sr
 
 // Host copies between caller memory and the pinned staging buffers are what bounds the PCIe-inclusive rate (one core moves
 // ~10 GB/s): large copies are cut into slices for a few short-lived threads.
+#ifndef LZ_COPY_THREADS
+#define LZ_COPY_THREADS 4
+#endif
 struct CopyJob { void* d; const void* s; size_t n; };
 void* copy_thread(void* a) { CopyJob* j = (CopyJob*)a; memcpy(j->d, j->s, j->n); return nullptr; }
 void par_memcpy(void* dst, const void* src, size_t n)
 {
-    const int kThreads = 4;
+    const int kThreads = LZ_COPY_THREADS;
     if (n < ((size_t)16 << 20)) { memcpy(dst, src, n); return; }
     pthread_t th[kThreads]; CopyJob job[kThreads]; bool started[kThreads];
     const size_t slice = ((n / kThreads) + 4095) & ~(size_t)4095;
