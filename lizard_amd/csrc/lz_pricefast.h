@@ -38,13 +38,17 @@
 //   LzTab18               u16 array + 2 bits per slot packed 16 to a dword (ds_mskor): 18-bit positions, i.e.
 //                         blocks <= 256 KiB — the benchmark configuration — in 36 KiB: four tables per CU instead
 //                         of three (the waves whose table is in LDS are ~5x faster than the others)
-//   LzTab32               u32 slots in global memory (one sector per access)
+//   LzTab32               u32 slots in global memory (one sector per access): 24-bit position + 8 check bits
 #define LZ_EMPTY24 0xFFFFFFu
 #define LZ_EMPTY18 0x3FFFFu
 struct LzTabPf24 {
     u16* lo; u8* hi;
     static constexpr u32 kEmpty = LZ_EMPTY24;
     static constexpr bool kSpecPut = true;
+    static constexpr bool kCheck = false;                        // no room for check bits beside the position
+    LZ_DEVM static u32 pos(u32 raw) { return raw; }
+    LZ_DEVM static u32 chk(u32) { return 0u; }
+    LZ_DEVM static u32 make(u32 p, u32) { return p; }
     LZ_DEVM void specPut(u32 h, u32 p) const { lo[h] = (u16)p; }
     LZ_DEVM bool specLost(u32 h, u32 p) const { return lo[h] != (u16)p; }
     LZ_DEVM u32  get(u32 h) const { return (u32)lo[h] | ((u32)hi[h] << 16); }
@@ -55,6 +59,10 @@ struct LzTab18 {
     u16* lo; u32* hi;
     static constexpr u32 kEmpty = LZ_EMPTY18;
     static constexpr bool kSpecPut = true;
+    static constexpr bool kCheck = false;
+    LZ_DEVM static u32 pos(u32 raw) { return raw; }
+    LZ_DEVM static u32 chk(u32) { return 0u; }
+    LZ_DEVM static u32 make(u32 p, u32) { return p; }
     LZ_DEVM void specPut(u32 h, u32 p) const { lo[h] = (u16)p; }
     LZ_DEVM bool specLost(u32 h, u32 p) const { return lo[h] != (u16)p; }
     LZ_DEVM u32  get(u32 h) const { return (u32)lo[h] | (((hi[h >> 4] >> (2u * (h & 15u))) & 3u) << 16); }
@@ -66,6 +74,13 @@ struct LzTab32 {
     u32* w;
     static constexpr u32 kEmpty = LZ_EMPTY24;
     static constexpr bool kSpecPut = false;
+    // The upper byte of a slot is a check hash of the 4 bytes at the stored position: a candidate whose check differs from
+    // the probing position's cannot pass the reference's 4-byte test (pricefast.h:67 / :109), so its bytes — a random
+    // 128-byte line of the block — are never fetched.
+    static constexpr bool kCheck = true;
+    LZ_DEVM static u32 pos(u32 raw) { return raw & 0xFFFFFFu; }
+    LZ_DEVM static u32 chk(u32 raw) { return raw >> 24; }
+    LZ_DEVM static u32 make(u32 p, u32 c) { return p | (c << 24); }
     LZ_DEVM void specPut(u32, u32) const {}
     LZ_DEVM bool specLost(u32, u32) const { return false; }
     LZ_DEVM u32  get(u32 h) const { return w[h]; }
@@ -195,7 +210,9 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
             havePre = false;
             const u32 first4 = (u32)bytes;
             const u32 h = lz_hash5<HASHLOG>(bytes);
-            u32 e = table.get(h);                                // pricefast.h:160,168 (old value; garbage when !valid)
+            const u32 myChk = TAB::kCheck ? (first4 * 2654435761u) >> 24 : 0u;
+            u32 e, ec;                                           // pricefast.h:160,168 (old value; garbage when !valid); its check bits
+            { const u32 raw = table.get(h); e = TAB::pos(raw); ec = TAB::chk(raw); }
             // Which lanes of this round share a table slot?  LDS tables: every lane stores the low half of its position
             // speculatively and reads the slot back — a lane that does not find its own value shares the slot with a later
             // lane (positions of a round differ by < 2^16); exact, no extra memory, settled after the winner is known.
@@ -214,28 +231,33 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
                 lz_lds_sync();                                   // tag reads done before the next round's writes
             }
             LZ_PROF(st, 8);                                      // (instrumented build) round: source + repeat bytes, hash, table read
-            const u32 eOld = e;
+            const u32 eOld = e, ecOld = ec;
             u64 pend = lz_ballot(lost);
             u64 grp = laneBit;
-            u32 tAfter = (e >= p || p >= e + LZ_MIN_OFFSET) ? p : e;     // pricefast.h:170-171 when alone in the slot
+            const bool putAlone = e >= p || p >= e + LZ_MIN_OFFSET;      // pricefast.h:170-171 when alone in the slot
+            u32 tAfter = putAlone ? p : e, tcAfter = putAlone ? myChk : ec;
             while (pend) {                                       // same-slot lanes: replay the puts in lane order
                 const u32 f = lz_ctz64(pend);
                 const u32 hv = lz_readlane(h, f);
                 const bool mine = valid && h == hv;
                 const u64 g = lz_ballot(mine);
                 u32 t = lz_readlane(e, f);                       // slot value before this round (uniform)
+                u32 tc = TAB::kCheck ? lz_readlane(ec, f) : 0u;  // ... and its check bits
                 for (u64 m = g; m; m &= m - 1ull) {
                     const u32 k = lz_ctz64(m), pk = ip + k;
-                    if (lane == k) e = t;
-                    t = (t >= pk || pk >= t + LZ_MIN_OFFSET) ? pk : t;
-                    if (lane == k) tAfter = t;
+                    const u32 ck = TAB::kCheck ? lz_readlane(myChk, k) : 0u;
+                    if (lane == k) { e = t; ec = tc; }
+                    const bool put = t >= pk || pk >= t + LZ_MIN_OFFSET;
+                    t = put ? pk : t; tc = put ? ck : tc;
+                    if (lane == k) { tAfter = t; tcAfter = tc; }
                 }
                 if (mine) grp = g;
                 pend &= ~g;
             }
             LZ_PROF(st, 9);                                      // round: same-slot replay
             // Lizard_FindMatchFast, pricefast.h:3-87: the repeat offset wins and hides the hash candidate
-            const bool hashCand = valid && e < p && e >= lowPos && p - e >= LZ_MIN_OFFSET;                  // :63-65
+            const bool hashCand = valid && e < p && e >= lowPos && p - e >= LZ_MIN_OFFSET                   // :63-65
+                                  && (!TAB::kCheck || ec == myChk);                                         // differing check bits: the 4-byte test (:67) would fail
             const u32 c4 = lz_ld32(src + (hashCand ? e : S));
             const bool rep = repCand && rep4 == first4;                                                     // :19-31
             bool hashOk = !rep && hashCand && c4 == first4;                                                 // :67
@@ -256,9 +278,9 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
                 // lanes happened (all after the winner) is restored by its first lane (whose `e` is still the old value)
                 const u64 c = grp & commit;
                 const bool writer = valid && (c ? (c >> lane) == 1ull : (grp & lanesBelow) == 0);
-                if (writer) table.set(h, c ? tAfter : eOld);
+                if (writer) table.set(h, c ? TAB::make(tAfter, tcAfter) : TAB::make(eOld, ecOld));
             } else {
-                if ((commit & laneBit) && (grp & commit & ~(lanesBelow | laneBit)) == 0) table.set(h, tAfter);
+                if ((commit & laneBit) && (grp & commit & ~(lanesBelow | laneBit)) == 0) table.set(h, TAB::make(tAfter, tcAfter));
             }
             table.sync();
             LZ_PROF(st, 11);                                     // round: table put
@@ -307,19 +329,25 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
             if (ip + ml >= mflimit) goto encode;                                          // :185
             start2 = ip + ml - 2u;
             {
-                u32 h2, e2;
+                u32 h2, e2, c2 = 0, chk2 = 0;
                 if (useSpec) { h2 = lz_readlane(hSpec, specIdx); e2 = lz_readlane(eSpec, specIdx); }
-                else { h2 = lz_hash5<HASHLOG>(lz_ld64(src + start2)); e2 = table.get(h2); }
+                else {
+                    const u64 b2 = lz_ld64(src + start2);
+                    h2 = lz_hash5<HASHLOG>(b2);
+                    const u32 raw2 = table.get(h2);
+                    e2 = TAB::pos(raw2); c2 = TAB::chk(raw2);
+                    chk2 = TAB::kCheck ? ((u32)b2 * 2654435761u) >> 24 : 0u;
+                }
                 useSpec = false;                                                          // later passes look elsewhere
                 const u32 low2 = start2 > maxDist ? start2 - maxDist : 0u;
                 ml2 = 0; back2 = 0;
-                if (e2 < start2 && e2 >= low2 && start2 - e2 >= LZ_MIN_OFFSET) {                            // :106-110
+                if (e2 < start2 && e2 >= low2 && start2 - e2 >= LZ_MIN_OFFSET && c2 == chk2) {              // :106-110 (check bits differ: :109 fails)
                     u32 mlt;                                                      // 4-byte test, length and :195-201 in one round trip
                     lz_count_both(src, start2, e2, matchlimit, ip, mlt, back2);
                     if (mlt >= 4u && (mlt >= LZ_MM_LONGOFF || start2 - e2 < LZ_16BIT_OFFSET)) { ml2 = mlt; ref2 = e2; }   // :112
                 }
                 table.sync();
-                if (lane == 0 && (e2 >= start2 || start2 >= e2 + LZ_MIN_OFFSET)) table.set(h2, start2);   // :190-191
+                if (lane == 0 && (e2 >= start2 || start2 >= e2 + LZ_MIN_OFFSET)) table.set(h2, TAB::make(start2, chk2));   // :190-191
                 table.sync();
             }
             LZ_PROF(st, 1);                                      // lazy re-search (table get/set, candidate, count)
