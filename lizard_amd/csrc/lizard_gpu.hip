@@ -69,7 +69,7 @@ struct LzBatch {
 #endif
 
 // NLDS of the W waves keep their hash table in LDS (form LDSKIND), the others in the wave's global-memory slot.
-template <int PARSER, int HASHLOG, int AUX, bool HUF, int W, int WSWORDS, int NLDS = (HASHLOG > 14 ? 0 : W), u32 LDSKIND = LZ_TABKIND_LDS, int POOL = 0>
+template <int PARSER, int HASHLOG, int AUX, bool HUF, int W, int WSWORDS, int NLDS = (HASHLOG > 14 ? 0 : W), u32 LDSKIND = LZ_TABKIND_LDS, int POOL = 0, int OCCLOG = 0, int WIDETAGLOG = LZ_WIDE_TAGLOG>
 __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
 {
     struct Slice { u64 ring[LZ_SEQ_RING]; u32 ws[WSWORDS]; };
@@ -86,6 +86,9 @@ __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
     __shared__ u32 hufPoolMask;
     // hashChain: the chain build of a block borrows one of HCPOOL 32 KiB regions (lz_hc_build)
     constexpr int HCPOOL = PARSER == LZ_PARSER_HASHCHAIN ? (HUF ? LZ_HC_POOL : LZ_HC_POOL + 1) : 0;   // the Huffman workspaces take a region's worth of LDS
+    // levels 11 / 31: occupancy summary of the wave's 2^18-slot table (LzTabWide::occ), 2^OCCLOG bits + a spare word
+    constexpr u32 kOccWords = OCCLOG ? ((1u << OCCLOG) >> 5) + 1u : 1u;
+    __shared__ u32 wideOcc[OCCLOG ? W : 1][kOccWords];
     static_assert(!(POOL != 0 && HCPOOL != 0), "one pool mask per workgroup");
     __shared__ u32 hcPoolMem[HCPOOL ? HCPOOL : 1][HCPOOL ? LZ_HC_REGION_WORDS : 1];
     if constexpr (POOL != 0 || HCPOOL != 0) { if (threadIdx.x == 0) hufPoolMask = 0; __syncthreads(); }
@@ -113,7 +116,7 @@ __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
         const u32 c = lz_compress_block<PARSER, HASHLOG, AUX, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
                                                                   a.level, tableMem, ws, scratch, my.ring, tabKind,
                                                                   POOL ? &hufPool[0][0] : nullptr, POOL ? &hufPoolMask : nullptr, (u32)POOL,
-                                                                  &hcPool, (u32)a.blockSize);
+                                                                  &hcPool, (u32)a.blockSize, OCCLOG ? wideOcc[OCCLOG ? wave : 0] : nullptr, (u32)OCCLOG, (u32)WIDETAGLOG);
         if (lz_lane() == 0) a.sizes[b] = c;
         lz_converge();
     }
@@ -137,10 +140,15 @@ void lz_fast12_kernel(LzBatch a)
 
 // levels 11 / 31: fast parser, 2^18-slot table (u32 slots, 1 MiB per wave in global memory: L2 / Infinity Cache)
 #define LZ_WAVES_FAST18 16
+#ifndef LZ_WIDE_OCC
+#define LZ_WIDE_OCC 1
+#endif
 template <bool HUF>
 __global__ __launch_bounds__(64 * LZ_WAVES_FAST18) void lz_fast18_kernel(LzBatch a)
 {
-    lz_wave_main<LZ_PARSER_FAST, 18, 0, HUF, LZ_WAVES_FAST18, (HUF ? LZ_HUF_WS_WORDS : (1u << LZ_WIDE_TAGLOG) / 4u)>(a);
+    // tag array: 1 KiB (with Huffman: the 2 KiB workspace doubles as it); occupancy summary: 8 KiB (4 slots per bit; 4 KiB with Huffman)
+    lz_wave_main<LZ_PARSER_FAST, 18, 0, HUF, LZ_WAVES_FAST18, (HUF ? LZ_HUF_WS_WORDS : (1u << 10) / 4u), 0, LZ_TABKIND_LDS, 0,
+                 (LZ_WIDE_OCC ? (HUF ? 15 : 16) : 0), (HUF ? LZ_WIDE_TAGLOG : 10)>(a);
 }
 
 // levels 13-17 / 34-38: hashChain parser (searchLength 5 for rows 13-15, 4 for 16-17; searchNum comes from the

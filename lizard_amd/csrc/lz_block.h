@@ -350,14 +350,31 @@ template <int HASHLOG> LZ_DEV void lz_tab_fresh(const LzTab& t) { lz_tab_sweep<H
 #endif
 struct LzTabWide {
     u32* w;
-    u8* tag;                                                                     // LDS, 2^LZ_WIDE_TAGLOG bytes
+    u8* tag;                                                                     // LDS, tagMask + 1 bytes
+    u32 tagMask = (1u << LZ_WIDE_TAGLOG) - 1u;
+    // Occupancy summary (LDS, optional): bit (h >> occShift) is set once a slot of its group has been written in this block.
+    // A probe whose bit is clear finds an empty slot without touching the table: with 2^18 slots and at most 2^17 insertions
+    // per 256 KiB block most probes do — and a probe is a random 128-byte line.
+    u32* occ = nullptr;
+    u32 occShift = 0;
     static constexpr bool kSweeps = false;
     static constexpr bool kTagDedup = true;
     static constexpr bool kXchg = false;
     LZ_DEVM u32 xchg(u32, u32) const { return 0; }
     LZ_DEVM u32  entry(u32 p, u32 first4) const { return p | ((first4 * 2654435761u) >> 22 << 22); }
-    LZ_DEVM u32  get(u32 h) const { return w[h]; }
-    LZ_DEVM void set(u32 h, u32 ent) const { w[h] = ent; }
+    LZ_DEVM u32  get(u32 h) const
+    {
+        if (!occ) return w[h];
+        const u32 b = h >> occShift;
+        const bool oc = (occ[b >> 5] >> (b & 31u)) & 1u;
+        const u32 v = w[oc ? h : 0u];                                            // unconditional load (slot 0 for the lanes that need none)
+        return oc ? v : 0xFFFFFFFFu;
+    }
+    LZ_DEVM void set(u32 h, u32 ent) const
+    {
+        w[h] = ent;
+        if (occ) { const u32 b = h >> occShift; lz_lds_atomic_or(&occ[b >> 5], 1u << (b & 31u)); }   // (the trash slot sets the spare bit)
+    }
     LZ_DEVM u32  age(u32 p, u32 ent) const { return p - (ent & 0x3FFFFFu); }     // empty / not-before-p slots wrap to > 65535
     LZ_DEVM bool sameCheck(u32 a, u32 b) const { return ((a ^ b) >> 22) == 0; }
     LZ_DEVM bool lostPut(u32 h, u32 mine) const { return w[h] != mine; }
@@ -368,6 +385,7 @@ template <int HASHLOG> LZ_DEV void lz_tab_fresh(const LzTabWide& t)
 {
     uint4 ff; ff.x = ff.y = ff.z = ff.w = 0xFFFFFFFFu;
     for (u32 i = lz_lane() * 4u; i < (1u << HASHLOG) + 4u; i += 256u) *(uint4*)(t.w + i) = ff;   // 16 B per lane, aligned base
+    if (t.occ) for (u32 i = lz_lane(); i < (((1u << HASHLOG) >> t.occShift) >> 5) + 1u; i += 64u) t.occ[i] = 0u;
 }
 
 // Position handled by `slot` of the current run.  A run that follows a match ("special") spends its first
@@ -451,7 +469,7 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
             e = table.get(h);                                            // value before this round
             bool lost;
             if constexpr (TAB::kTagDedup) {                              // same-slot lanes found through LDS; nothing stored yet
-                const u32 ti = h & ((1u << LZ_WIDE_TAGLOG) - 1u);
+                const u32 ti = h & table.tagMask;
                 if (valid) table.tag[ti] = (u8)lane;
                 lz_lds_sync();
                 lost = valid && table.tag[ti] != (u8)lane;
@@ -681,7 +699,7 @@ LZ_DEV u32 lz_write_subblock_seq(const u8* src, u32 S, u32 E, u8* op, LzStreams&
 template <int PARSER, int HASHLOG, int AUX, bool HUF>
 LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tableMem, u8* ws, u8* scratch, u64* seqRing,
                              u32 tabKind = LZ_TABKIND_LDS, u32* hufPoolBase = nullptr, u32* hufPoolMask = nullptr, u32 hufPoolCount = 0,
-                             const LzHufPool* hcPool = nullptr, u32 maxBlock = 0)
+                             const LzHufPool* hcPool = nullptr, u32 maxBlock = 0, u32* wideOcc = nullptr, u32 wideOccLog = 0, u32 wideTagLog = LZ_WIDE_TAGLOG)
 {
     const u32 lane = lz_lane();
     LzStreams st;
@@ -694,7 +712,8 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
     // fast parser: 24-bit LDS slots up to hashLog 14, wide u32 slots in global memory above
     constexpr bool kWide = PARSER == LZ_PARSER_FAST && HASHLOG > 14;
     LzTab tab = lz_tab_bind<kWide ? 1 : HASHLOG>(tableMem);
-    LzTabWide tabw; tabw.w = (u32*)tableMem; tabw.tag = ws;
+    LzTabWide tabw; tabw.w = (u32*)tableMem; tabw.tag = ws; tabw.tagMask = (1u << wideTagLog) - 1u;
+    if constexpr (PARSER == LZ_PARSER_FAST && HASHLOG > 14) { tabw.occ = wideOcc; tabw.occShift = wideOcc ? (u32)HASHLOG - wideOccLog : 0u; }
     LzTabPf24 pf24; pf24.lo = tab.lo; pf24.hi = tab.hi;
     LzTab32 pf32; pf32.w = (u32*)tableMem;
     LzTab18 pf18; pf18.lo = (u16*)tableMem; pf18.hi = (u32*)((u8*)tableMem + (2u << (kWide ? 1 : HASHLOG)));

@@ -5,7 +5,7 @@
 #include "../../lizard_amd/csrc/lz_unpack.h"
 
 namespace {
-struct Args { const u8* src; u32 n; u8* dst; u32 level; u32* table; u8* tag; u8* scratch; u64* ring; u32 result; u32 tabKind; u32* hcRegion; u32 maxBlock; u32 poolMask; };
+struct Args { const u8* src; u32 n; u8* dst; u32 level; u32* table; u8* tag; u8* scratch; u64* ring; u32 result; u32 tabKind; u32* hcRegion; u32 maxBlock; u32 poolMask; u32* wideOcc; };
 
 template <int PARSER, int HASHLOG, int AUX, bool HUF>
 void entry_block(void* a)
@@ -13,7 +13,7 @@ void entry_block(void* a)
     Args* x = (Args*)a;
     LzHufPool hcPool; hcPool.base = x->hcRegion; hcPool.mask = &x->poolMask; hcPool.count = 1; hcPool.stride = LZ_HC_REGION_WORDS;   // a pool of one chain-build region
     u32 r = lz_compress_block<PARSER, HASHLOG, AUX, HUF>(x->src, x->n, x->dst, x->level, x->table, x->tag, x->scratch, x->ring, x->tabKind,
-                                                         nullptr, nullptr, 0, &hcPool, x->maxBlock);
+                                                         nullptr, nullptr, 0, &hcPool, x->maxBlock, x->wideOcc, x->wideOcc ? 16u : 0u);
     if (lz_lane() == 0) x->result = r;
 }
 }  // namespace
@@ -58,6 +58,8 @@ extern "C" int emul_compress_block(const void* src, int n, void* dst, int level,
     void* garbageTable = a.table;
     if (hcLevel) a.table = (u32*)hc_slot();
     a.maxBlock = (u32)kHcMaxBlock; a.poolMask = 0;
+    a.wideOcc = (base == 11 && !(seed & 2u)) ? (u32*)malloc(8192 + 8) : nullptr;     // levels 11/31: with and without the occupancy summary
+    if (a.wideOcc) memset(a.wideOcc, 0x77, 8192 + 8);
     a.hcRegion = (u32*)aligned_alloc(64, 4 * LZ_HC_REGION_WORDS + 64);
     memset(a.hcRegion, 0x3C, 4 * LZ_HC_REGION_WORDS);
     switch (base) {
@@ -68,7 +70,7 @@ extern "C" int emul_compress_block(const void* src, int n, void* dst, int level,
     case 21: lzemu::run_wave(huf ? entry_block<LZ_PARSER_PRICEFAST, 14, 12, true> : entry_block<LZ_PARSER_PRICEFAST, 14, 12, false>, &a, seed); break;
     default: lzemu::run_wave(huf ? entry_block<LZ_PARSER_PRICEFAST, 18, 12, true> : entry_block<LZ_PARSER_PRICEFAST, 18, 12, false>, &a, seed); break;
     }
-    free(garbageTable); free(a.tag); free(a.scratch); free(a.hcRegion);
+    free(garbageTable); free(a.tag); free(a.scratch); free(a.hcRegion); free(a.wideOcc);
     return (int)a.result;
 }
 
