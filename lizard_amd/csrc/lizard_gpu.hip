@@ -64,6 +64,9 @@ struct LzBatch {
 #endif
 #define LZ_WAVES_FASTLDS      13             // all tables in LDS (blocks above 4 MiB)
 #define LZ_WAVES_FASTLDS_HUF  11
+#ifndef LZ_WIDE_OCC
+#define LZ_WIDE_OCC 1                        // occupancy summaries of the 2^18-slot global tables (levels 11/31, 22/42)
+#endif
 #ifndef LZ_MAX_WAVES
 #define LZ_MAX_WAVES          16             // scratch / table slots per CU
 #endif
@@ -140,9 +143,6 @@ void lz_fast12_kernel(LzBatch a)
 
 // levels 11 / 31: fast parser, 2^18-slot table (u32 slots, 1 MiB per wave in global memory: L2 / Infinity Cache)
 #define LZ_WAVES_FAST18 16
-#ifndef LZ_WIDE_OCC
-#define LZ_WIDE_OCC 1
-#endif
 template <bool HUF>
 __global__ __launch_bounds__(64 * LZ_WAVES_FAST18) void lz_fast18_kernel(LzBatch a)
 {
@@ -214,7 +214,9 @@ __global__ __launch_bounds__(64 * (SMALL ? (HUF ? LZ_PF18_W_HUF : LZ_PF18_W) : L
 template <bool HUF>
 __global__ __launch_bounds__(64 * LZ_PF22_W) void lz_pricefast18_kernel(LzBatch a)
 {
-    lz_wave_main<LZ_PARSER_PRICEFAST, 18, LZ_PF_TAGLOG, HUF, LZ_PF22_W, (HUF ? LZ_HUF_WS_WORDS : (1u << LZ_PF_TAGLOG) / 4u), 0>(a);
+    // tag array 1 KiB (with Huffman: the 2 KiB workspace doubles as it); occupancy summary of the table 8 KiB (4 KiB with Huffman)
+    lz_wave_main<LZ_PARSER_PRICEFAST, 18, (HUF ? LZ_PF_TAGLOG : 10), HUF, LZ_PF22_W, (HUF ? LZ_HUF_WS_WORDS : (1u << 10) / 4u), 0, LZ_TABKIND_LDS, 0,
+                 (LZ_WIDE_OCC ? (HUF ? 15 : 16) : 0)>(a);
 }
 
 // Decompression: one wave per block, same persistent grid; block b is read from

@@ -716,6 +716,7 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
     if constexpr (PARSER == LZ_PARSER_FAST && HASHLOG > 14) { tabw.occ = wideOcc; tabw.occShift = wideOcc ? (u32)HASHLOG - wideOccLog : 0u; }
     LzTabPf24 pf24; pf24.lo = tab.lo; pf24.hi = tab.hi;
     LzTab32 pf32; pf32.w = (u32*)tableMem;
+    if constexpr (PARSER == LZ_PARSER_PRICEFAST && HASHLOG > 14) { pf32.occ = wideOcc; pf32.occShift = wideOcc ? (u32)HASHLOG - wideOccLog : 0u; }
     LzTab18 pf18; pf18.lo = (u16*)tableMem; pf18.hi = (u32*)((u8*)tableMem + (2u << (kWide ? 1 : HASHLOG)));
     LzHc hc;
     if constexpr (PARSER == LZ_PARSER_HASHCHAIN) {

@@ -81,14 +81,32 @@ struct LzTab32 {
     LZ_DEVM static u32 pos(u32 raw) { return raw & 0xFFFFFFu; }
     LZ_DEVM static u32 chk(u32 raw) { return raw >> 24; }
     LZ_DEVM static u32 make(u32 p, u32 c) { return p | (c << 24); }
+    // Occupancy summary (LDS, optional; levels 22/42 with their 2^18 slots): as LzTabWide::occ in lz_block.h
+    u32* occ = nullptr;
+    u32 occShift = 0;
     LZ_DEVM void specPut(u32, u32) const {}
     LZ_DEVM bool specLost(u32, u32) const { return false; }
-    LZ_DEVM u32  get(u32 h) const { return w[h]; }
-    LZ_DEVM void set(u32 h, u32 v) const { w[h] = v; }
+    LZ_DEVM u32  get(u32 h) const
+    {
+        if (!occ) return w[h];
+        const u32 b = h >> occShift;
+        const bool oc = (occ[b >> 5] >> (b & 31u)) & 1u;
+        const u32 v = w[oc ? h : 0u];
+        return oc ? v : LZ_EMPTY24;
+    }
+    LZ_DEVM void set(u32 h, u32 v) const
+    {
+        w[h] = v;
+        if (occ) { const u32 b = h >> occShift; lz_lds_atomic_or(&occ[b >> 5], 1u << (b & 31u)); }
+    }
     LZ_DEVM void sync() const { lz_wave_sync(); }
 };
 template <int HASHLOG> LZ_DEV void lz_pf_tab_fresh(const LzTabPf24& t) { for (u32 i = lz_lane(); i < (1u << HASHLOG); i += 64u) t.set(i, LZ_EMPTY24); }
-template <int HASHLOG> LZ_DEV void lz_pf_tab_fresh(const LzTab32& t) { for (u32 i = lz_lane(); i < (1u << HASHLOG); i += 64u) t.w[i] = LZ_EMPTY24; }
+template <int HASHLOG> LZ_DEV void lz_pf_tab_fresh(const LzTab32& t)
+{
+    for (u32 i = lz_lane(); i < (1u << HASHLOG); i += 64u) t.w[i] = LZ_EMPTY24;
+    if (t.occ) for (u32 i = lz_lane(); i < (((1u << HASHLOG) >> t.occShift) >> 5); i += 64u) t.occ[i] = 0u;
+}
 template <int HASHLOG> LZ_DEV void lz_pf_tab_fresh(const LzTab18& t)
 {
     for (u32 i = lz_lane(); i < (1u << HASHLOG) / 2u; i += 64u) ((u32*)t.lo)[i] = 0xFFFFFFFFu;

@@ -58,7 +58,7 @@ extern "C" int emul_compress_block(const void* src, int n, void* dst, int level,
     void* garbageTable = a.table;
     if (hcLevel) a.table = (u32*)hc_slot();
     a.maxBlock = (u32)kHcMaxBlock; a.poolMask = 0;
-    a.wideOcc = (base == 11 && !(seed & 2u)) ? (u32*)malloc(8192 + 8) : nullptr;     // levels 11/31: with and without the occupancy summary
+    a.wideOcc = ((base == 11 || base == 22) && !(seed & 2u)) ? (u32*)malloc(8192 + 8) : nullptr;     // levels 11/31, 22/42: with and without the occupancy summary
     if (a.wideOcc) memset(a.wideOcc, 0x77, 8192 + 8);
     a.hcRegion = (u32*)aligned_alloc(64, 4 * LZ_HC_REGION_WORDS + 64);
     memset(a.hcRegion, 0x3C, 4 * LZ_HC_REGION_WORDS);
