@@ -192,19 +192,25 @@ __global__ __launch_bounds__(64 * LZ_WAVES_HC) void lz_hashchain_kernel(LzBatch 
 #ifndef LZ_PF18_TAGLOG
 #define LZ_PF18_TAGLOG 11
 #endif
+#ifndef LZ_PF18_HUF_POOL
+#define LZ_PF18_HUF_POOL 3                 // Huffman workspaces shared by the waves of a level-41 workgroup (0 = one each: 3 LDS tables + 9)
+#endif
 #ifndef LZ_PF18_W_HUF
-#define LZ_PF18_W_HUF 12
+#define LZ_PF18_W_HUF (LZ_PF18_HUF_POOL ? 10 : 12)
 #endif
 #ifndef LZ_PF18_NLDS_HUF
-#define LZ_PF18_NLDS_HUF 3
+#define LZ_PF18_NLDS_HUF (LZ_PF18_HUF_POOL ? 4 : 3)
 #endif
 #define LZ_PF_SLOT_BYTES 65536u
 template <bool HUF, bool SMALL>
 __global__ __launch_bounds__(64 * (SMALL ? (HUF ? LZ_PF18_W_HUF : LZ_PF18_W) : LZ_PF_W)) void lz_pricefast14_kernel(LzBatch a)
 {
     if constexpr (SMALL)
-        lz_wave_main<LZ_PARSER_PRICEFAST, 14, (HUF ? 11 : LZ_PF18_TAGLOG), HUF, (HUF ? LZ_PF18_W_HUF : LZ_PF18_W),
-                     (HUF ? LZ_HUF_WS_WORDS : 1), (HUF ? LZ_PF18_NLDS_HUF : LZ_PF18_NLDS), LZ_TABKIND_LDS18>(a);
+        // level 41: the Huffman workspaces come from a pool (the parse is most of a wave's time), which leaves room for as many
+        // LDS tables as level 21 has
+        lz_wave_main<LZ_PARSER_PRICEFAST, 14, (HUF ? (LZ_PF18_HUF_POOL ? 10 : 11) : LZ_PF18_TAGLOG), HUF, (HUF ? LZ_PF18_W_HUF : LZ_PF18_W),
+                     (HUF && !LZ_PF18_HUF_POOL ? LZ_HUF_WS_WORDS : 1), (HUF ? LZ_PF18_NLDS_HUF : LZ_PF18_NLDS), LZ_TABKIND_LDS18,
+                     (HUF ? LZ_PF18_HUF_POOL : 0)>(a);
     else
         lz_wave_main<LZ_PARSER_PRICEFAST, 14, LZ_PF_TAGLOG, HUF, LZ_PF_W, (HUF ? LZ_HUF_WS_WORDS : 1),
                      (HUF ? LZ_PF_NLDS_HUF : LZ_PF_NLDS)>(a);
