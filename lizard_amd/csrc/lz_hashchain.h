@@ -10,9 +10,9 @@
 //     order (nextToUpdate only moves forward), and what it writes for position p — the distance from p to
 //     the head of p's hash bucket at that moment, and the conditional head update ":38" — depends only on
 //     positions < p.  A search at X starts from the head "after inserting everything below X", which is
-//     exactly what Insert recorded for X itself.  So the chain is built AHEAD of the parse, 64 positions
-//     per step (phase A, lz_hc_build), into prev[p] = distance to the previous head (0 = none inside the
-//     64 KiB window), one u16 per block position; the searches of phase B never touch the head table.
+//     exactly what Insert recorded for X itself.  So the chain is built AHEAD of the parse (phase A,
+//     lz_hc_build), into prev[p] = distance to the previous head (0 = none inside the 64 KiB window), one
+//     u16 per block position; the searches of phase B never touch a head table.
 //     (Positions the reference never inserts — the tail after the last search — are invisible: a search at
 //     X only ever follows links that start below X.  The reference never searches below nextToUpdate —
 //     every search position exceeds the previous one, see the walk through :207-339 in DESIGN.md — and
@@ -23,10 +23,11 @@
 //     window); here it is stored as 0 = end of chain.  A true distance of exactly 65535 stays usable.
 //   * Head table: never exists as a 2^18-slot array.  lz_hc_build brings the positions into hash-bin order and replays
 //     each bin against a 2^12-slot table in LDS (blocks up to 4 MiB: 22-bit positions).
-//   * Phase B: the outer "ip++ until a position has a match" loop (:204-206) runs 64 consecutive positions
-//     per round, each lane walking its own chain until the first candidate that passes the reference's
-//     tests (any such candidate makes ml >= 4 > 0); the first such lane is the position the reference
-//     stops at.  From there on the LZ4HC-style arbitration is a serial chain per sequence and runs as
+//   * Phase B: the outer "ip++ until a position has a match" loop (:204-206) stops at the first position one
+//     of whose first searchNum chain candidates passes the reference's tests (any such candidate makes
+//     ml >= 4 > 0) — a function of the position alone, evaluated for all positions ahead of the parse
+//     (lz_hc_hits) into one bit each; the loop is a scan of those bits.  From there on the LZ4HC-style
+//     arbitration is a serial chain per sequence and runs as
 //     wave-uniform code; each search collects up to 64 chain candidates (one per lane), filters them in
 //     parallel on the 4-byte test and measures the survivors with the wave-wide compare helpers.  The
 //     reference's "first strictly longer match wins" over the chain order is "maximum length, earliest
