@@ -389,7 +389,14 @@ LZ_DEV u32 lz_decompress_block(const u8* in, u32 inSize, u8* out, u32 outCap, u8
                 const u32 token = lz_readlane(tokv, t);
                 // a 256-byte window of the literals stream at lp: the escapes of this sequence (and, fastLZ4, its offset when
                 // the literal run is short) are in it
-                const u32 wv = lp + 4u * lane + 4u <= nl ? lz_ld32(pl + lp + 4u * lane) : 0u;
+                // (the stream's last dword is put together byte by byte: its bytes below nl count — an escape may sit in the last
+                //  1..3 bytes of the stream, lizard_decompress_liz.h:142 only asks for literalsPtr <= iend - 1)
+                u32 wv = 0;
+                {
+                    const u32 wa = lp + 4u * lane;
+                    if (wa + 4u <= nl) wv = lz_ld32(pl + wa);
+                    else for (u32 k = 0; k < 4u; k++) if (wa + k < nl) wv |= (u32)pl[wa + k] << (8u * k);
+                }
                 u32 L, ml, off, used = 0;                        // used: bytes of the window consumed before the literals
                 if (lz4) {                                       // lizard_decompress_lz4.h:41-110
                     L = token & 15u;

@@ -61,6 +61,61 @@ def test_emulated_decoder_refuses_or_survives_damage():
             assert r == -1 or 0 <= r <= len(data)
 
 
+def _le24(v):
+    return bytes([v & 255, (v >> 8) & 255, (v >> 16) & 255])
+
+
+def _block(level, flags, lits, off16=b"", off24=b""):
+    """One hand-built block of one sub-block, all streams raw (container: lizard_compress.c:186-250)."""
+    return bytes([level, 0]) + _le24(0) + _le24(len(off16)) + off16 + _le24(len(off24)) + off24 + _le24(len(flags)) + flags + _le24(len(lits)) + lits
+
+
+def _short_tail_vectors():
+    """(block, plain, the reference decoder accepts it).  Blocks the encoders never write but the format allows: a length
+    escape in the last 1..3 bytes of the literals stream (lizard_decompress_liz.h:142 only asks for literalsPtr <= iend - 1).
+    The reference's wild copies make it refuse some of them (a token >= 32 needs 16 more literal-stream bytes,
+    lizard_decompress_liz.h:81; fastLZ4 literals end 18 bytes before the stream does, lizard_decompress_lz4.h:68): those are
+    only checked against the hand-built expectation."""
+    abc = bytes(range(97, 97 + 26)) + b"0123"
+    out = []
+    # LIZv1: token 39 = [0 0100 111]: L escape (30 literals), ml 4, new 16-bit offset 8; then a 24-bit-offset token 31 whose
+    # match-length escape is the last 1 / 3 / 4 bytes of the literals stream
+    for esc, v in ((bytes([3]), 3), (bytes([254, 0x10, 0x01]), 0x110), (bytes([255, 1, 2, 0]), 0x201), (bytes([200]), 200)):
+        plain = bytearray(abc)
+        for _ in range(4): plain.append(plain[len(plain) - 8])
+        for _ in range(v + 31 + 16): plain.append(plain[len(plain) - 10])
+        out.append((_block(20, bytes([39, 31]), bytes([23]) + abc + esc, off16=bytes([8, 0]), off24=bytes([10, 0, 0])), bytes(plain), True))
+    # LIZv1: [1 1111 000] repeat-offset match whose ml escape (token field 15) ends the stream, after a plain first sequence
+    for esc, v in ((bytes([9]), 9), (bytes([254, 1, 1]), 0x101)):
+        plain = bytearray(abc)
+        for _ in range(4): plain.append(plain[len(plain) - 8])
+        for _ in range(v + 15): plain.append(plain[len(plain) - 8])
+        out.append((_block(20, bytes([39, 0xF8]), bytes([23]) + abc + esc, off16=bytes([8, 0])), bytes(plain), False))
+    # fastLZ4: the offset + a 4-byte match-length escape 8 bytes before the end of the stream, at every alignment of the offset
+    for pad in range(4):
+        lits = bytes((i * 7 + pad) & 255 for i in range(70000 + pad))
+        v = 0x011234                                                   # 24-bit escape with a non-zero top byte
+        rec = bytes([255]) + _le24(len(lits) - 15) + lits + bytes([40, 0]) + bytes([255]) + _le24(v) + b"zz"
+        plain = bytearray(lits)
+        for _ in range(v + 15 + 4): plain.append(plain[len(plain) - 40])
+        out.append((_block(10, bytes([0xFF]), rec), bytes(plain) + b"zz", False))
+    return out
+
+
+def test_emulated_decoder_short_tail_escapes():
+    ref = util.reference()
+    accepted = 0
+    for i, (comp, plain, ref_ok) in enumerate(_short_tail_vectors()):
+        if ref is not None:                                            # (the reference wants 16 bytes of slack behind a match)
+            dst = ctypes.create_string_buffer(len(plain) + 64)
+            r = ref.Lizard_decompress_safe(comp, dst, len(comp), len(plain) + 32)
+            assert (r == len(plain) and dst.raw[:len(plain)] == plain) if ref_ok else r < 0, i
+            accepted += r > 0
+        r, out = emul_decompress(comp, len(plain))
+        assert r == len(plain) and out == plain, i
+    assert ref is None or accepted == 4
+
+
 @pytest.fixture(scope="module")
 def L():
     from lizard_amd import _lib
@@ -146,3 +201,12 @@ def test_gpu_decoder_survives_damage(L):
         rc = L.LizardGPU_decompressBlocks_host(buf.ctypes.data, offs.ctypes.data, len(bad_blocks), out.ctypes.data, len(data), sz.ctypes.data)
         assert rc == 0
         assert all(s == 0xFFFFFFFF or s <= len(data) for s in sz)
+
+
+@pytest.mark.gpu
+def test_gpu_decoder_short_tail_escapes(L):
+    """The hand-built blocks of test_emulated_decoder_short_tail_escapes through the one-block twin on the device."""
+    for i, (comp, plain, _) in enumerate(_short_tail_vectors()):
+        dst = ctypes.create_string_buffer(len(plain) + 8)
+        assert L.LizardGPU_decompress_safe(comp, dst, len(comp), len(plain)) == len(plain), i
+        assert dst.raw[:len(plain)] == plain, i
