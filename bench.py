@@ -25,6 +25,14 @@ Per config:
   blocks_checked / blocks_checked_bytes   after the timed region EVERY block's compressed size is compared with the
                 zero-state reference (oracle/_ref/liblizard_ref_reset.so, else the oracle restatement) run on the host
                 cores, and >= 2 048 blocks byte for byte
+  roofline.traffic_source  which committed counter pass `traffic` comes from (file, round, commit) — `traffic` is null, and this
+                says so, when the device sources (lizard_amd/csrc/lz_*.h) no longer hash to what that pass was measured on
+  cpu_baseline_all_cores   the same stock reference library in N processes pinned to N host CPUs at once (N stated), each
+                looping over its own blocks like programs/bench.c:233-255: the honest per-node CPU figure
+"blocks_in_flight" (level 10, 4 MiB blocks): GB/s against the number of blocks of a launch — one wave per block, so a launch
+needs about as many blocks as the chip has resident waves before it runs at speed.
+N > 1: the size gather is the library's (LizardGPU_gatherSizes_device over RCCL); if it cannot be set up or fails the run FAILS —
+there is no torch.distributed fallback — and "per_rank" lists every rank's mean kernel ms and gather us.
 "end_to_end" is the PCIe-inclusive rate of the host-buffer entry (LizardGPU_compressBlocks_host_packed) on a 4 GiB sample
 of the headline workload, from pageable and from pinned memory — never `value`.
 Only the cpu_baseline / verification legs touch oracle/ (as the checker); the timed region calls the product library.
@@ -42,6 +50,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+from tools import datagen as tools_datagen      # bench / test tooling: the synthetic-workload generator (not in the product library)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -62,6 +71,85 @@ def kernel_name(level, bs):
     if base == 22:
         return "lz_pricefast18_kernel<%s>" % huf
     return "lz_hashchain_kernel<%s, %d>" % (huf, 5 if base <= 15 else 4)
+
+
+def kernel_source_sha16():
+    """Hash of the device sources (every lz_*.h of lizard_amd/csrc): what a committed counter pass was measured on."""
+    import hashlib
+    d = os.path.join(ROOT, "lizard_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.startswith("lz_") and f.endswith(".h"):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def lookup_traffic(level, bs, nb):
+    """(traffic bytes per launch | None, traffic_source): the LAST matching entry of profiles/pmc_traffic.json, only if it
+    was measured on the device sources of this tree."""
+    cur = kernel_source_sha16()
+    ent = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            for e in json.load(f)["entries"]:
+                if (e["level"], e["block_size"], e["blocks_per_gpu"]) == (level, bs, nb):
+                    ent = e
+    except (OSError, KeyError, ValueError):
+        pass
+    if ent is None:
+        return None, {"file": None, "note": "no counter pass recorded for this configuration", "kernel_source_sha16": cur}
+    src = {"file": ent.get("source"), "round": ent.get("round"), "commit": ent.get("commit"),
+           "measured_on_kernel_source_sha16": ent.get("kernel_source_sha16"), "kernel_source_sha16": cur,
+           "how": "separate rocprofv3 --pmc passes, not measured in this run"}
+    if ent.get("kernel_source_sha16") != cur:
+        src["stale"] = True
+        src["stale_traffic_bytes"] = ent["traffic_bytes"]
+        return None, src
+    return ent["traffic_bytes"], src
+
+
+def _all_cores_child(cpu, level, bs, nblocks, seconds, start, out, idx):
+    os.sched_setaffinity(0, {cpu})
+    import util
+    fn, _ = load_checker(zero_state=False)
+    buf = ctypes.create_string_buffer(nblocks * bs)
+    base = ctypes.addressof(buf)
+    for b in range(nblocks):
+        util.oracle().lzo_datagen(base + b * bs, bs, 0.5, 0.0, idx * nblocks + b)
+    bound = util.oracle().lzo_compress_bound(bs)
+    dst = ctypes.create_string_buffer(bound)
+    start.wait()
+    t0 = time.perf_counter(); done = 0
+    while True:                                             # programs/bench.c:233-241: block after block through Lizard_compress
+        for b in range(nblocks):
+            fn(base + b * bs, dst, bs, bound, level)
+            done += 1
+        if time.perf_counter() - t0 >= seconds:
+            break
+    out[2 * idx] = done * bs
+    out[2 * idx + 1] = time.perf_counter() - t0
+
+
+def cpu_all_cores(level, bs, nblocks, seconds):
+    """N processes pinned to the N CPUs this process may run on, all compressing at once; whole-node MB/s."""
+    import multiprocessing as mp
+    cpus = sorted(os.sched_getaffinity(0))
+    ctx = mp.get_context("fork")
+    start = ctx.Barrier(len(cpus) + 1)
+    out = ctx.Array("d", 2 * len(cpus), lock=False)
+    procs = [ctx.Process(target=_all_cores_child, args=(c, level, bs, nblocks, seconds, start, out, i)) for i, c in enumerate(cpus)]
+    for p in procs: p.start()
+    start.wait()
+    for p in procs: p.join()
+    if any(p.exitcode for p in procs):
+        raise SystemExit("cpu_all_cores: a worker failed")
+    tot = sum(out[2 * i] for i in range(len(cpus)))
+    tmax = max(out[2 * i + 1] for i in range(len(cpus)))
+    _, kind = load_checker(zero_state=False)
+    return {"value": round(tot / tmax / 1e6, 1), "unit": "MB/s", "cores": len(cpus), "kind": kind,
+            "sample": f"{len(cpus)} processes pinned one per logical CPU, each looping over its own {nblocks} blocks x {bs} B "
+                      f"(datagen P50) through Lizard_compress level {level} for >= {seconds} s, all at once",
+            "per_process_mb_s": round(tot / tmax / 1e6 / len(cpus), 1)}
 
 
 def load_checker(zero_state):
@@ -87,10 +175,10 @@ def cpu_baseline(L, level, block_size, n_blocks, budget_s, seed0=0, whole_buffer
     buf = ctypes.create_string_buffer(n_blocks * block_size)
     base = ctypes.addressof(buf)
     if whole_buffer:
-        L.LizardGPU_datagen_host(base, n_blocks * block_size, 0.5, 0.0, seed0)
+        tools_datagen.datagen_host(base, n_blocks * block_size, 0.5, 0.0, seed0)
     else:
         for b in range(n_blocks):
-            L.LizardGPU_datagen_host(base + b * block_size, block_size, 0.5, 0.0, seed0 + b)
+            tools_datagen.datagen_host(base + b * block_size, block_size, 0.5, 0.0, seed0 + b)
     bound = util.oracle().lzo_compress_bound(block_size)
     out = ctypes.create_string_buffer(bound)
     best, total_c, t_start, loops = None, 0, time.perf_counter(), 0
@@ -150,7 +238,7 @@ def verify_all_blocks(L, level, bs, nb, src, dst, sizes, stride, seed0, byte_blo
             if c0 == 0:                                     # device datagen == host datagen (what the workload claims to be)
                 blk = ctypes.create_string_buffer(bs)
                 for b in (0, 1, c1 - 1):
-                    L.LizardGPU_datagen_host(blk, bs, 0.5, 0.0, seed0 + b)
+                    tools_datagen.datagen_host(blk, bs, 0.5, 0.0, seed0 + b)
                     assert host[(b - c0) * bs:(b - c0 + 1) * bs].tobytes() == blk.raw, f"device datagen differs from host datagen at block {b}"
     return nb, n_bytes_checked, kind
 
@@ -168,7 +256,14 @@ def main():
     ap.add_argument("--cpu-blocks", type=int, default=256)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / verification / end-to-end legs")
     ap.add_argument("--headline-only", action="store_true")
+    ap.add_argument("--cpu-all-seconds", type=float, default=3.0, help="all-cores CPU baseline: seconds per level (0 = skip)")
+    ap.add_argument("--cpu-all-cores-worker", nargs=4, type=float, default=None, metavar=("LEVEL", "BS", "NBLOCKS", "SECONDS"),
+                    help="internal: run the all-cores CPU baseline in this (GPU-free) process and print its JSON")
     args = ap.parse_args()
+    if args.cpu_all_cores_worker:
+        lv, bs_, nbk, sec = args.cpu_all_cores_worker
+        print(json.dumps(cpu_all_cores(int(lv), int(bs_), int(nbk), sec)))
+        return
 
     import numpy as np
     import torch
@@ -188,21 +283,20 @@ def main():
     L = _lib.lib()
     _lib.check(L.LizardGPU_setDevice(local_rank), "LizardGPU_setDevice")
 
-    # the RCCL size gather lives in the library (rccl.h); the launcher's transport only carries the 128-byte id
+    # the RCCL size gather lives in the library (rccl.h); the launcher's transport only carries the 128-byte id.
+    # No fallback: a job whose library communicator cannot be made fails here.
     gather_via = "none (1 GPU)"
     if world > 1:
-        try:
-            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
-            if rank == 0:
-                buf = ctypes.create_string_buffer(128)
-                _lib.check(L.LizardGPU_commUniqueId(buf), "LizardGPU_commUniqueId")
-                uid.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
-            dist.broadcast(uid, 0)
-            _lib.check(L.LizardGPU_commInitRank(bytes(uid.cpu().numpy().tobytes()), world, rank), "LizardGPU_commInitRank")
-            gather_via = "library: ncclAllGather via LizardGPU_gatherSizes_device"
-        except Exception as e:                                  # keep the job alive on the collective torch already has
-            gather_via = f"torch.distributed all_gather (library communicator unavailable: {e})"
-            print(f"bench.py rank {rank}: {gather_via}", file=sys.stderr)
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            _lib.check(L.LizardGPU_commUniqueId(buf), "LizardGPU_commUniqueId")
+            uid.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        _lib.check(L.LizardGPU_commInitRank(bytes(uid.cpu().numpy().tobytes()), world, rank), "LizardGPU_commInitRank")
+        L.LizardGPU_rcclShared.restype = ctypes.c_int
+        gather_via = ("library: ncclAllGather via LizardGPU_gatherSizes_device (RCCL "
+                      + ("shared with torch" if L.LizardGPU_rcclShared() == 1 else "loaded by the library") + ")")
 
     if args.level is not None:
         plan = [(args.level, args.block_size, args.blocks or 16384)]
@@ -215,7 +309,6 @@ def main():
     src_all = torch.empty(max_in, dtype=torch.uint8, device=dev)
     dst_all = torch.empty(max_out, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev)
-    from lizard_amd.sharding import gather_block_sizes
     threads = max(1, min(96, (os.cpu_count() or 8) - 2))
     state = {"gather": gather_via}
 
@@ -234,11 +327,12 @@ def main():
         all_sizes = torch.zeros(world * nb, dtype=torch.int32, device=dev)
         offsets = torch.zeros(world * nb + 1, dtype=torch.int64, device=dev)
         seed0 = rank * nb
-        _lib.check(L.LizardGPU_datagen_device(src.data_ptr(), nb, bs, 0.5, 0.0, seed0, ctypes.c_void_p(stream.cuda_stream)),
-                   "LizardGPU_datagen_device")
+        tools_datagen.datagen_device(src.data_ptr(), nb, bs, 0.5, 0.0, seed0, ctypes.c_void_p(stream.cuda_stream))
         torch.cuda.synchronize()
         kernel_ms = []
         gathered = [None]
+
+        gather_ev = []
 
         def step(timed):
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -246,17 +340,15 @@ def main():
             api.compress_blocks_device(src, bs, level, dst=dst, sizes=sizes)
             e1.record(stream)
             if world > 1:                                     # RCCL over xGMI: 4 B per block per rank
-                rc = -1
-                if state["gather"].startswith("library"):
-                    rc = L.LizardGPU_gatherSizes_device(sizes.data_ptr(), world * nb, all_sizes.data_ptr(), offsets.data_ptr(),
-                                                        ctypes.c_void_p(stream.cuda_stream))
-                    if rc == 0:
-                        gathered[0] = (all_sizes, offsets[:-1])
-                    else:                                     # keep the job alive on the collective torch already has (same on every rank)
-                        state["gather"] = "torch.distributed all_gather (library gather failed: %s)" % L.LizardGPU_lastError().decode(errors="replace")
-                        print(f"bench.py rank {rank}: {state['gather']}", file=sys.stderr)
+                rc = L.LizardGPU_gatherSizes_device(sizes.data_ptr(), world * nb, all_sizes.data_ptr(), offsets.data_ptr(),
+                                                    ctypes.c_void_p(stream.cuda_stream))
                 if rc != 0:
-                    gathered[0] = gather_block_sizes(sizes, world * nb)
+                    raise SystemExit(f"bench.py rank {rank}: LizardGPU_gatherSizes_device failed ({rc}): "
+                                     + L.LizardGPU_lastError().decode(errors="replace"))
+                gathered[0] = (all_sizes, offsets[:-1])
+                if timed:
+                    e2 = torch.cuda.Event(enable_timing=True); e2.record(stream)
+                    gather_ev.append((e1, e2))
             if timed:
                 kernel_ms.append((e0, e1))
 
@@ -273,6 +365,13 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         kms = [a.elapsed_time(b) for a, b in kernel_ms]
+        per_rank = None
+        if world > 1:                                        # every rank's mean kernel ms and gather us, gathered for the line
+            mine = torch.tensor([sum(kms) / len(kms), 1e3 * sum(a.elapsed_time(b) for a, b in gather_ev) / max(1, len(gather_ev))],
+                                dtype=torch.float64, device=dev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = [{"rank": r, "kernel_ms": round(float(t[0]), 3), "gather_us": round(float(t[1]), 1)} for r, t in enumerate(allr)]
         in_bytes = nb * bs
         out_bytes = int(sizes.to(torch.int64).sum().item())
         tot_in, tot_out = in_bytes * world, out_bytes
@@ -285,14 +384,7 @@ def main():
         if rank == 0:
             avg_k = sum(kms) / len(kms) / 1e3
             alg_bytes = in_bytes + out_bytes                     # per launch on this GPU
-            traffic = None                                       # fabric bytes per launch from the committed PMC passes
-            try:
-                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                    for ent in json.load(f)["entries"]:
-                        if (ent["level"], ent["block_size"], ent["blocks_per_gpu"]) == (level, bs, nb):
-                            traffic = ent["traffic_bytes"]        # the LAST matching entry (latest round) wins
-            except (OSError, KeyError, ValueError):
-                pass
+            traffic, traffic_source = lookup_traffic(level, bs, nb)   # fabric bytes per launch from a committed counter pass of THESE kernels, else null
             res = {
                 "level": level, "block_size": bs, "blocks_per_gpu": nb,
                 "workload": f"level -{level}, {nb} x {bs} B independent blocks per GPU, datagen P50 "
@@ -302,14 +394,26 @@ def main():
                 "ratio": round(tot_in / tot_out, 4), "compressed_bytes": tot_out,
                 "roofline": {"bound": "hbm", "achieved": round(alg_bytes / avg_k / 1e9, 2), "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": round(alg_bytes / avg_k / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic,
+                             "traffic_source": traffic_source,
                              "traffic_over_algorithmic": round(traffic / alg_bytes, 2) if traffic else None,
                              "kernel": kernel_name(level, bs), "avg_kernel_ms": round(avg_k * 1e3, 3),
                              "algorithmic_bytes_per_launch": alg_bytes},
             }
+            if per_rank:
+                res["per_rank"] = per_rank
             if with_cpu:                            # the CPU legs: the only place the oracle / oracle/_ref is touched
                 ncpu = min(args.cpu_blocks if bs <= (1 << 20) else 32, nb)
                 res["cpu_baseline"], _ = cpu_baseline(L, level, bs, ncpu, args.cpu_seconds)
                 res["speedup_vs_cpu_1core"] = round(res["value"] / res["cpu_baseline"]["value"], 2)
+                if args.cpu_all_seconds > 0 and bs <= (1 << 20):
+                    import subprocess
+                    w = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-all-cores-worker", str(level), str(bs), "32", str(args.cpu_all_seconds)],
+                                       capture_output=True, text=True, timeout=300)
+                    if w.returncode == 0:
+                        res["cpu_baseline_all_cores"] = json.loads(w.stdout.strip().splitlines()[-1])
+                        res["speedup_vs_cpu_all_cores"] = round(res["value"] / res["cpu_baseline_all_cores"]["value"], 2)
+                    else:
+                        res["cpu_baseline_all_cores"] = {"error": w.stderr[-300:]}
                 if args.verify > 0:
                     t0 = time.perf_counter()
                     n_sz, n_by, kind = verify_all_blocks(L, level, bs, nb, src, dst, sizes, stride, seed0, args.verify, threads)
@@ -341,11 +445,31 @@ def main():
             "ratio": head["ratio"], "compressed_bytes": head["compressed_bytes"],
             "roofline": head["roofline"],
         }
-        for k in ("cpu_baseline", "speedup_vs_cpu_1core", "blocks_checked", "blocks_checked_bytes", "checker"):
+        for k in ("cpu_baseline", "speedup_vs_cpu_1core", "cpu_baseline_all_cores", "speedup_vs_cpu_all_cores", "per_rank",
+                  "blocks_checked", "blocks_checked_bytes", "checker"):
             if k in head:
                 out[k] = head[k]
         if len(results) > 1:
             out["configs"] = results[1:]
+        if world == 1 and args.level is None and not args.headline_only:
+            # one wave = one block: what a launch of fewer blocks than resident waves reaches (level 10, 4 MiB blocks; src_all still holds them)
+            bs4 = 4 << 20
+            stride4 = (api.Lizard_compressBound(bs4) + 63) & ~63
+            curve = []
+            for nbk in (256, 512, 1024, 3328, 6656):
+                sz4 = torch.zeros(nbk, dtype=torch.int32, device=dev)
+                ms = []
+                for it in range(3):
+                    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    api.compress_blocks_device(src_all[:nbk * bs4], bs4, 10, dst=dst_all[:nbk * stride4], sizes=sz4)
+                    e1.record(stream)
+                    torch.cuda.synchronize()
+                    if it:
+                        ms.append(e0.elapsed_time(e1))
+                curve.append({"blocks": nbk, "GB_s": round(nbk * bs4 / (sum(ms) / len(ms)) / 1e6, 1)})
+            out["blocks_in_flight"] = {"workload": "level -10, 4 MiB blocks (the CLI's default block size), datagen P50, device-resident, kernel time",
+                                       "resident_waves": int(L.LizardGPU_residentWaves()), "curve": curve}
         if with_cpu and args.level is None:
             # BASELINE configs[0]: the reference's own CPU-runnable case, and the GPU on exactly that buffer
             c1, hostbuf = cpu_baseline(L, 10, 262144, 256, args.cpu_seconds, seed0=0, whole_buffer=True)
@@ -357,8 +481,7 @@ def main():
             out["config1"] = c1
             # PCIe-inclusive rate of the host-buffer entry on a 4 GiB sample of the headline workload (never `value`)
             nbe = min(16384, head["blocks_per_gpu"]); bs = 262144
-            _lib.check(L.LizardGPU_datagen_device(src_all.data_ptr(), nbe, bs, 0.5, 0.0, 0, ctypes.c_void_p(stream.cuda_stream)),
-                       "LizardGPU_datagen_device")
+            tools_datagen.datagen_device(src_all.data_ptr(), nbe, bs, 0.5, 0.0, 0, ctypes.c_void_p(stream.cuda_stream))
             torch.cuda.synchronize()
             host = src_all[:nbe * bs].cpu()
             cap = nbe * api.Lizard_compressBound(bs)

@@ -85,7 +85,10 @@ enum {
     LIZARDGPU_ERR_ARG = 3,           /* bad size / stride / null pointer */
     LIZARDGPU_ERR_HIP = 4,           /* a HIP call failed (see LizardGPU_lastError) */
     LIZARDGPU_ERR_NOMEM = 5,         /* device or pinned-host allocation failed */
-    LIZARDGPU_ERR_RCCL = 6           /* RCCL could not be loaded or a collective failed */
+    LIZARDGPU_ERR_RCCL = 6,          /* RCCL could not be loaded or a collective failed */
+    LIZARDGPU_ERR_HARDWARE = 7       /* the device failed the library's self-check of a property the level's kernel relies on:
+                                      * lanes of one LDS atomic that hit the same dword are served in ascending lane order
+                                      * (checked once per device at context creation; levels 10/30 and the hashChain levels) */
 };
 
 /* 1 if `compressionLevel` (after the reference's clamp, lib/lizard_compress.c:303-308) runs on the GPU:
@@ -163,6 +166,21 @@ int  LizardGPU_commInitRank(const void* id128, int nRanks, int rank);
 int  LizardGPU_gatherSizes_device(const uint32_t* d_localSizes, size_t nBlocks, uint32_t* d_allSizes,
                                   uint64_t* d_offsets, void* stream);
 int  LizardGPU_commDestroy(void);
+/* The transport of the size exchange is a table of four calls (u32 elements; `comm` and `stream` are passed through as the
+ * library received them; allGather is in place when send == recv + rank*count, as ncclAllGather; every call returns 0 or a
+ * negative LIZARDGPU_ERR_*).  RCCL fills it by default — resolved from a copy the process has already mapped (torch's in a
+ * torchrun job) before librccl.so.1 is loaded, LizardGPU_rcclShared() = 1 / 0 / -1 (not resolved yet).  LizardGPU_setCollectives
+ * installs another transport (NULL: back to RCCL); with one installed, LizardGPU_compressBlocks_sharded passes the rank index
+ * as `comm` and makes no communicator.  The exchange logic itself (lizard_amd/csrc/lizard_shard_core.h) is transport-agnostic:
+ * tests/shard_fake.cpp runs it with 2 and 3 ranks over shared memory on a CPU. */
+typedef struct {
+    int (*allGather)(const void* send, void* recv, size_t count, void* comm, void* stream);
+    int (*broadcast)(const void* send, void* recv, size_t count, int root, void* comm, void* stream);
+    int (*groupStart)(void);
+    int (*groupEnd)(void);
+} LizardGPU_Collectives;
+int  LizardGPU_setCollectives(const LizardGPU_Collectives* table);
+int  LizardGPU_rcclShared(void);
 
 /* ---- decompression ----
  * Independent blocks as Lizard_decompress_safe() decodes them (reference lib/lizard_decompress.h:64, lizard_decompress.c:267;
@@ -179,13 +197,6 @@ int LizardGPU_decompressBlocks_host(const void* src, const uint64_t* offsets, si
                                     uint32_t* outSizes);
 int LizardGPU_decompress_safe(const char* source, char* dest, int compressedSize, int maxDecompressedSize);
 
-/* Synthetic input, the reference's benchmark generator (programs/datagen.c:153 RDG_genBuffer).
- * Host: fills buffer[0..size) exactly like RDG_genBuffer(buffer, size, matchProba, litProba, seed).
- * Device: block b (b < nBlocks, blockSize bytes each, back to back at d_dst) is
- * RDG_genBuffer(blockSize, matchProba, litProba, seed0 + b); synchronous. */
-void LizardGPU_datagen_host(void* buffer, size_t size, double matchProba, double litProba, unsigned seed);
-int  LizardGPU_datagen_device(void* d_dst, size_t nBlocks, size_t blockSize, double matchProba, double litProba,
-                              unsigned seed0, void* stream);
 
 /* Kernel-only duration of the most recent LizardGPU_compressBlocks_* call on the selected device, measured with HIP
  * events on the launch stream, in milliseconds (blocks until that launch finished; host-buffer calls: the sum over

@@ -54,10 +54,6 @@ def lib():
     L.LizardGPU_compressBlocks_host.argtypes = [c.c_void_p, c.c_size_t, c.c_size_t, c.c_size_t, c.c_void_p,
                                                 c.c_size_t, c.c_void_p, c.c_int]
     L.LizardGPU_compressBlocks_host.restype = c.c_int
-    L.LizardGPU_datagen_host.argtypes = [c.c_void_p, c.c_size_t, c.c_double, c.c_double, c.c_uint]
-    L.LizardGPU_datagen_host.restype = None
-    L.LizardGPU_datagen_device.argtypes = [c.c_void_p, c.c_size_t, c.c_size_t, c.c_double, c.c_double, c.c_uint, c.c_void_p]
-    L.LizardGPU_datagen_device.restype = c.c_int
     L.LizardGPU_compressBlocks_host_packed.argtypes = [c.c_void_p, c.c_size_t, c.c_size_t, c.c_size_t, c.c_void_p,
                                                        c.c_size_t, c.c_void_p, c.c_void_p, c.c_int]
     L.LizardGPU_compressBlocks_host_packed.restype = c.c_int

@@ -1,12 +1,7 @@
 // lizard_gpu.hip — gfx950 kernels + the thin extern "C" shim the host C layer (lizard_host.c) calls.
 //
-// Launch geometry: ONE wavefront per Lizard API block.  The grid is persistent — one workgroup of up to
-// 16 independent waves per CU (they never synchronise with each other) — and every wave pulls block indices
-// from a device counter, so tail blocks do not strand CUs.  Each wave owns a hash table (LDS slice or
-// global-memory slot, see lz_wave_main) and a scratch slot in a global arena (sequence list / Huffman staging,
-// written and re-read once per sub-block).  Blocks never communicate: no inter-workgroup synchronisation.
-//
-// Host side of this file: one context PER DEVICE (arenas, tables, streams, pinned staging), a per-thread device
+// The kernels live in lz_kernels.h (one wavefront per Lizard API block, a persistent grid of one workgroup per CU).
+// This file: one context PER DEVICE (arenas, tables, streams, pinned staging), a per-thread device
 // selection and error text, the pipelined host-buffer path (pinned double-buffered staging, device-side
 // compaction of the compressed blocks, one D2H per chunk) and the single-process multi-device entry with an
 // RCCL all-gather of the per-block sizes (lizard_shard.h).
@@ -19,245 +14,9 @@
 
 #include "../../include/lizard_amd.h"
 #include "lizard_gpu_shim.h"
-#include "lz_block.h"
-#include "lz_datagen.h"
-#include "lz_pack.h"
-#include "lz_unpack.h"
+#include "lz_kernels.h"   // LzBatch / LzUnBatch, residency knobs, the kernels
 
 namespace {
-
-struct LzBatch {
-    const u8* src;  u64 blockSize;  u32 nBlocks;  u32 lastBlockSize;
-    u8* dst;        u64 dstStride;  u32* sizes;   u32 level;
-    u8* scratch;    u32* counter;
-    u8* tables;     // per resident wave, for the waves whose hash table is not in LDS: levels 10/30/21/41 a 64 KiB slot,
-                    // levels 11/31/22/42 LZ_TABWIDE_BYTES(18), hashChain levels LZ_HC_SLOT_BYTES(maxBlock)
-    u64 tableStride;
-};
-
-// Residency by construction.  LDS is what limits the number of tables in flight, and the hardware hands it out
-// in 512-byte granules per WORKGROUP: thirteen independent 64-thread workgroups of 12 560 B each get 12 800 B
-// apiece, so only twelve fit in a CU's 160 KiB (the occupancy API, which divides raw sizes, says thirteen).
-// Instead ONE workgroup per CU carries W waves and private slices of one allocation; NLDS of them keep their
-// hash table in LDS, the others in a global-memory slot (DESIGN.md section 4 lists the split per level).
-// The splits are compile-time knobs so that tuning variants can be built side by side (lizard_amd/variants).
-// Level 10: all thirteen waves keep their table in LDS.  Three more waves with 16 KiB tables in global memory (12 + 4)
-// were 2.5 % faster but doubled the fabric traffic of a launch (156 GB instead of 77 GB for 27 GB of algorithmic bytes):
-// every put into a global table leaves L2 as a 32-byte write, and the tables' lines are re-fetched at 128 bytes.
-#ifndef LZ_WAVES_FAST
-#define LZ_WAVES_FAST      13
-#endif
-#ifndef LZ_NLDS_FAST
-#define LZ_NLDS_FAST       13
-#endif
-#ifndef LZ_WAVES_FAST_HUF
-#define LZ_WAVES_FAST_HUF  16
-#endif
-#ifndef LZ_NLDS_FAST_HUF
-#define LZ_NLDS_FAST_HUF   11
-#endif
-#ifndef LZ_HC_POOL
-#define LZ_HC_POOL         3              // chain-build regions (32.3 KiB each) shared by the waves of a hashChain workgroup (one more without Huffman)
-#endif
-#ifndef LZ_HUF_POOL
-#define LZ_HUF_POOL        5              // Huffman workspaces shared by the 16 waves of a level-30 workgroup (0 = one each)
-#endif
-#define LZ_WAVES_FASTLDS      13             // all tables in LDS (blocks above 4 MiB)
-#define LZ_WAVES_FASTLDS_HUF  11
-#ifndef LZ_WIDE_OCC
-#define LZ_WIDE_OCC 1                        // occupancy summaries of the 2^18-slot global tables (levels 11/31, 22/42)
-#endif
-#ifndef LZ_MAX_WAVES
-#define LZ_MAX_WAVES          16             // scratch / table slots per CU
-#endif
-
-// NLDS of the W waves keep their hash table in LDS (form LDSKIND), the others in the wave's global-memory slot.
-template <int PARSER, int HASHLOG, int AUX, bool HUF, int W, int WSWORDS, int NLDS = (HASHLOG > 14 ? 0 : W), u32 LDSKIND = LZ_TABKIND_LDS, int POOL = 0, int OCCLOG = 0, int WIDETAGLOG = LZ_WIDE_TAGLOG>
-__device__ __forceinline__ void lz_wave_main(const LzBatch& a)
-{
-    struct Slice { u64 ring[LZ_SEQ_RING]; u32 ws[WSWORDS]; };
-    constexpr u32 kTabWords = (LDSKIND == LZ_TABKIND_LDS18 ? LZ_TAB18_BYTES(HASHLOG) : LZ_TAB_BYTES(HASHLOG)) / 4u + 1u;
-    __shared__ u32 ldsTables[NLDS ? NLDS : 1][NLDS ? kTabWords : 1];
-    __shared__ Slice lds[W];
-    // mixed residency: only the global-table waves need a round tag array (LzTabWide / LzTab32; the LDS-table waves find
-    // same-slot lanes through the table itself); with the Huffman stage it aliases their workspace, without it they get
-    // their own here
-    constexpr bool kMixed = PARSER != LZ_PARSER_HASHCHAIN && NLDS != 0 && NLDS != W;
-    constexpr bool kOwnTags = kMixed && (!HUF || POOL != 0);
-    // POOL != 0: the waves borrow their Huffman workspace from a pool of POOL slots (lz_pool_acquire) instead of owning one
-    __shared__ u32 hufPool[POOL ? POOL : 1][POOL ? LZ_HUF_WS_WORDS : 1];
-    __shared__ u32 hufPoolMask;
-    // hashChain: the chain build of a block borrows one of HCPOOL 32 KiB regions (lz_hc_build)
-    constexpr int HCPOOL = PARSER == LZ_PARSER_HASHCHAIN ? (HUF ? LZ_HC_POOL : LZ_HC_POOL + 1) : 0;   // the Huffman workspaces take a region's worth of LDS
-    // levels 11 / 31: occupancy summary of the wave's 2^18-slot table (LzTabWide::occ), 2^OCCLOG bits + a spare word
-    constexpr u32 kOccWords = OCCLOG ? ((1u << OCCLOG) >> 5) + 1u : 1u;
-    __shared__ u32 wideOcc[OCCLOG ? W : 1][kOccWords];
-    static_assert(!(POOL != 0 && HCPOOL != 0), "one pool mask per workgroup");
-    __shared__ u32 hcPoolMem[HCPOOL ? HCPOOL : 1][HCPOOL ? LZ_HC_REGION_WORDS : 1];
-    if constexpr (POOL != 0 || HCPOOL != 0) { if (threadIdx.x == 0) hufPoolMask = 0; __syncthreads(); }
-    LzHufPool hcPool; hcPool.base = &hcPoolMem[0][0]; hcPool.mask = &hufPoolMask; hcPool.count = (u32)HCPOOL; hcPool.stride = LZ_HC_REGION_WORDS;
-    constexpr u32 kTagWords = (PARSER == LZ_PARSER_FAST ? (1u << LZ_WIDE_TAGLOG) : (1u << AUX)) / 4u;
-    __shared__ u32 wideTags[kOwnTags ? W - NLDS : 1][kOwnTags ? kTagWords : 1];
-    const u32 wave = lz_uniform(threadIdx.x >> 6);               // readfirstlane: the wave index (and everything derived from it) lives in SGPRs
-    Slice& my = lds[wave];
-    const u64 slot = (u64)blockIdx.x * LZ_MAX_WAVES + wave;
-    u8* scratch = a.scratch + slot * LZ_SCRATCH_BYTES;
-    void* tableMem;
-    if constexpr (NLDS == W)      tableMem = (void*)ldsTables[wave];
-    else if constexpr (NLDS == 0) tableMem = (void*)(a.tables + slot * a.tableStride);
-    else tableMem = wave < (u32)NLDS ? (void*)ldsTables[wave] : (void*)(a.tables + slot * a.tableStride);
-    const u32 tabKind = (NLDS != W && wave >= (u32)NLDS) ? LZ_TABKIND_GLOBAL : LDSKIND;
-    u8* const ws = (kOwnTags && tabKind == LZ_TABKIND_GLOBAL) ? (u8*)wideTags[kOwnTags ? wave - NLDS : 0] : (u8*)my.ws;
-#ifdef LZ_LDS_PRIO
-    if (tabKind != LZ_TABKIND_GLOBAL) __builtin_amdgcn_s_setprio(LZ_LDS_PRIO);   // the LDS-table waves are the fast ones: they issue first
-#endif
-    for (;;) {
-        lz_converge();
-        const u32 b = lz_claim_index(a.counter);
-        if (b >= a.nBlocks) break;
-        const u32 n = (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
-        const u32 c = lz_compress_block<PARSER, HASHLOG, AUX, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
-                                                                  a.level, tableMem, ws, scratch, my.ring, tabKind,
-                                                                  POOL ? &hufPool[0][0] : nullptr, POOL ? &hufPoolMask : nullptr, (u32)POOL,
-                                                                  &hcPool, (u32)a.blockSize, OCCLOG ? wideOcc[OCCLOG ? wave : 0] : nullptr, (u32)OCCLOG, (u32)WIDETAGLOG);
-        if (lz_lane() == 0) a.sizes[b] = c;
-        lz_converge();
-    }
-}
-
-// levels 10 / 30: fastSmall parser, 2^12-slot table + sequence ring (+ Huffman workspace).  MIXED: 16 waves, of which
-// 12 (5 with the Huffman workspaces) keep the 24-bit-slot table (12 KiB) in LDS and the others a u32-slot table
-// in global memory — full 22-bit positions there, hence blocks up to 4 MiB; larger blocks run the all-LDS form
-// (13 / 9 waves), whose 17-bit relative positions have no size limit.
-template <bool HUF, bool MIXED>
-__global__ __launch_bounds__(64 * (MIXED ? (HUF ? LZ_WAVES_FAST_HUF : LZ_WAVES_FAST) : (HUF ? LZ_WAVES_FASTLDS_HUF : LZ_WAVES_FASTLDS)))
-void lz_fast12_kernel(LzBatch a)
-{
-    if constexpr (MIXED)
-        lz_wave_main<LZ_PARSER_FAST, 12, 0, HUF, (HUF ? LZ_WAVES_FAST_HUF : LZ_WAVES_FAST), (HUF && !LZ_HUF_POOL ? LZ_HUF_WS_WORDS : 1),
-                     (HUF ? LZ_NLDS_FAST_HUF : LZ_NLDS_FAST), LZ_TABKIND_LDS, (HUF ? LZ_HUF_POOL : 0)>(a);
-    else
-        lz_wave_main<LZ_PARSER_FAST, 12, 0, HUF, (HUF ? LZ_WAVES_FASTLDS_HUF : LZ_WAVES_FASTLDS), (HUF ? LZ_HUF_WS_WORDS : 1),
-                     (HUF ? LZ_WAVES_FASTLDS_HUF : LZ_WAVES_FASTLDS)>(a);
-}
-
-// levels 11 / 31: fast parser, 2^18-slot table (u32 slots, 1 MiB per wave in global memory: L2 / Infinity Cache)
-#define LZ_WAVES_FAST18 16
-template <bool HUF>
-__global__ __launch_bounds__(64 * LZ_WAVES_FAST18) void lz_fast18_kernel(LzBatch a)
-{
-    // tag array: 1 KiB (with Huffman: the 2 KiB workspace doubles as it); occupancy summary: 8 KiB (4 slots per bit; 4 KiB with Huffman)
-    lz_wave_main<LZ_PARSER_FAST, 18, 0, HUF, LZ_WAVES_FAST18, (HUF ? LZ_HUF_WS_WORDS : (1u << 10) / 4u), 0, LZ_TABKIND_LDS, 0,
-                 (LZ_WIDE_OCC ? (HUF ? 15 : 16) : 0), (HUF ? LZ_WIDE_TAGLOG : 10)>(a);
-}
-
-// levels 13-17 / 34-38: hashChain parser (searchLength 5 for rows 13-15, 4 for 16-17; searchNum comes from the
-// level at run time).  Per wave: bins + chain array in global memory, Huffman workspace in LDS; the chain build of a
-// block borrows one of LZ_HC_POOL 32 KiB LDS regions of the workgroup.
-#ifndef LZ_WAVES_HC
-#define LZ_WAVES_HC 16
-#endif
-template <bool HUF, int SEARCHLEN>
-__global__ __launch_bounds__(64 * LZ_WAVES_HC) void lz_hashchain_kernel(LzBatch a)
-{
-    lz_wave_main<LZ_PARSER_HASHCHAIN, 18, SEARCHLEN, HUF, LZ_WAVES_HC, (HUF ? LZ_HUF_WS_WORDS : 1)>(a);
-}
-
-// levels 21 / 41: priceFast + LIZv1, 2^14-slot table.  The parse is a latency chain, so throughput follows the
-// number of resident waves, and a wave whose table is in LDS is several times faster than one that keeps it in a
-// global-memory slot (there every probe is a memory-side sector).  Two forms, chosen by block size:
-//   SMALL (blocks <= 256 KiB, the benchmark configuration): 18-bit positions packed into 36 KiB (LzTab18) — four
-//         tables per CU (two beside the sixteen 5.3 KiB Huffman workspaces of level 41);
-//   general (blocks < 16 MiB): 24-bit positions, 48 KiB (LzTabPf24) — two tables per CU (one at level 41).
-// The remaining waves of the workgroup keep u32 slots in their 64 KiB global-memory slot (LzTab32).
-#ifndef LZ_PF_W
-#define LZ_PF_W 12
-#endif
-#define LZ_PF22_W 16
-#ifndef LZ_PF_NLDS
-#define LZ_PF_NLDS 2
-#endif
-#ifndef LZ_PF_NLDS_HUF
-#define LZ_PF_NLDS_HUF 2
-#endif
-#ifndef LZ_PF_TAGLOG
-#define LZ_PF_TAGLOG 11
-#endif
-#ifndef LZ_PF18_W
-#define LZ_PF18_W 10
-#endif
-#ifndef LZ_PF18_NLDS
-#define LZ_PF18_NLDS 4
-#endif
-#ifndef LZ_PF18_TAGLOG
-#define LZ_PF18_TAGLOG 11
-#endif
-#ifndef LZ_PF18_HUF_POOL
-#define LZ_PF18_HUF_POOL 3                 // Huffman workspaces shared by the waves of a level-41 workgroup (0 = one each: 3 LDS tables + 9)
-#endif
-#ifndef LZ_PF18_W_HUF
-#define LZ_PF18_W_HUF (LZ_PF18_HUF_POOL ? 10 : 12)
-#endif
-#ifndef LZ_PF18_NLDS_HUF
-#define LZ_PF18_NLDS_HUF (LZ_PF18_HUF_POOL ? 4 : 3)
-#endif
-#define LZ_PF_SLOT_BYTES 65536u
-template <bool HUF, bool SMALL>
-__global__ __launch_bounds__(64 * (SMALL ? (HUF ? LZ_PF18_W_HUF : LZ_PF18_W) : LZ_PF_W)) void lz_pricefast14_kernel(LzBatch a)
-{
-    if constexpr (SMALL)
-        // level 41: the Huffman workspaces come from a pool (the parse is most of a wave's time), which leaves room for as many
-        // LDS tables as level 21 has
-        lz_wave_main<LZ_PARSER_PRICEFAST, 14, (HUF ? (LZ_PF18_HUF_POOL ? 10 : 11) : LZ_PF18_TAGLOG), HUF, (HUF ? LZ_PF18_W_HUF : LZ_PF18_W),
-                     (HUF && !LZ_PF18_HUF_POOL ? LZ_HUF_WS_WORDS : 1), (HUF ? LZ_PF18_NLDS_HUF : LZ_PF18_NLDS), LZ_TABKIND_LDS18,
-                     (HUF ? LZ_PF18_HUF_POOL : 0)>(a);
-    else
-        lz_wave_main<LZ_PARSER_PRICEFAST, 14, LZ_PF_TAGLOG, HUF, LZ_PF_W, (HUF ? LZ_HUF_WS_WORDS : 1),
-                     (HUF ? LZ_PF_NLDS_HUF : LZ_PF_NLDS)>(a);
-}
-
-// levels 22 / 42: priceFast + LIZv1 with a 2^18-slot table: 1 MiB of u32 slots per wave, all in global memory
-template <bool HUF>
-__global__ __launch_bounds__(64 * LZ_PF22_W) void lz_pricefast18_kernel(LzBatch a)
-{
-    // tag array 1 KiB (with Huffman: the 2 KiB workspace doubles as it); occupancy summary of the table 8 KiB (4 KiB with Huffman)
-    lz_wave_main<LZ_PARSER_PRICEFAST, 18, (HUF ? LZ_PF_TAGLOG : 10), HUF, LZ_PF22_W, (HUF ? LZ_HUF_WS_WORDS : (1u << 10) / 4u), 0, LZ_TABKIND_LDS, 0,
-                 (LZ_WIDE_OCC ? (HUF ? 15 : 16) : 0)>(a);
-}
-
-// Decompression: one wave per block, same persistent grid; block b is read from
-// src + offsets[b] (packed form) or src + b * srcStride (slot form), srcSizes[b] bytes.
-struct LzUnBatch {
-    const u8* src; const u64* offsets; u64 srcStride; const u32* srcSizes;
-    u8* dst; u64 dstStride; u32* outSizes; u32 nBlocks;
-    u8* scratch; u32* counter;
-};
-#define LZ_WAVES_DEC 16
-__global__ __launch_bounds__(64 * LZ_WAVES_DEC) void lz_decompress_kernel(LzUnBatch a)
-{
-    __shared__ u32 ws[LZ_WAVES_DEC][LZD_WS_WORDS];
-    const u32 wave = lz_uniform(threadIdx.x >> 6);
-    u8* stage = a.scratch + ((u64)blockIdx.x * LZ_MAX_WAVES + wave) * LZ_SCRATCH_BYTES;     // 4 x LZD_STAGE_BYTES fit a scratch slot
-    for (;;) {
-        lz_converge();
-        const u32 b = lz_claim_index(a.counter);
-        if (b >= a.nBlocks) break;
-        const u8* in = a.offsets ? a.src + a.offsets[b] : a.src + (u64)b * a.srcStride;
-        const u32 n = a.offsets ? (u32)(a.offsets[b + 1] - a.offsets[b]) : a.srcSizes[b];
-        const u32 cap = a.dstStride > 0x7E000000ull ? 0x7E000000u : (u32)a.dstStride;
-        const u32 r = lz_decompress_block(in, n, a.dst + (u64)b * a.dstStride, cap, stage, ws[wave]);
-        if (lz_lane() == 0) a.outSizes[b] = r;
-        lz_converge();
-    }
-}
-
-// synthetic input: one thread per block, block b = RDG_genBuffer(blockSize, P, seed0 + b)
-__global__ __launch_bounds__(64) void lz_datagen_kernel(u8* dst, u64 nBlocks, u64 blockSize, u32 matchProba32,
-                                                        int zeroRuns, const u8* lt, u32 seed0)
-{
-    const u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nBlocks) lz_rdg_fill(dst + b * blockSize, (size_t)blockSize, matchProba32, zeroRuns, lt, seed0 + (u32)b);
-}
 
 // ------------------------------------------------------------------------------------------------
 // One stage of the host-buffer pipeline: pinned staging on the host side, input / slot / packed buffers on the
@@ -285,9 +44,9 @@ struct Ctx {
     size_t hcMaxBlock = 0;
     u8*   scratch = nullptr;
     u32*  counter = nullptr;
-    u8*   d_lt = nullptr;       // datagen literal table
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool  timed = false;
+    bool  laneOrderOk = true;   // self-check at context creation: lanes of one DS atomic are served in lane order (lz_selfcheck_lane_order_kernel)
     float hostKernelMs = -1.0f; // sum over the chunks of the last host-buffer call (< 0: last call was a device call)
     Stage stage[LZ_STAGES];
     pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
@@ -376,6 +135,21 @@ int ctx_init(Ctx& c)
         LZ_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
         LZ_HIP(hipEventCreateWithFlags(&s.up, hipEventDisableTiming));
     }
+    // Self-check of the hardware property the exchange round (levels 10/30) and the hashChain build rely on.  A device that
+    // fails it keeps working for the other levels; the dependent ones are refused, loudly (launch()).
+    // LIZARDGPU_FORCE_LANE_ORDER_FAILURE=1 takes the failure branch on a healthy device (tests).
+    {
+        LZ_HIP(hipMemset(c.counter, 0, 4));
+        hipLaunchKernelGGL(lz_selfcheck_lane_order_kernel, dim3(16), dim3(64), 0, 0, c.counter, 256u);
+        LZ_HIP(hipGetLastError());
+        u32 bad = 0;
+        LZ_HIP(hipMemcpy(&bad, c.counter, 4, hipMemcpyDeviceToHost));
+        const char* force = getenv("LIZARDGPU_FORCE_LANE_ORDER_FAILURE");
+        c.laneOrderOk = bad == 0 && !(force && force[0] == '1');
+        if (!c.laneOrderOk)
+            fprintf(stderr, "liblizard_amd: device %d: lanes of one LDS atomic are NOT served in lane order (%u violations%s); "
+                            "levels 10, 30, 13-17 and 34-38 are refused on this device\n", c.device, bad, bad ? "" : ", forced by LIZARDGPU_FORCE_LANE_ORDER_FAILURE");
+    }
     c.ready = true;
     return 0;
 }
@@ -427,11 +201,10 @@ void ctx_release(Ctx& c)
     if (c.hcSlots) (void)hipFree(c.hcSlots);
     if (c.scratch) (void)hipFree(c.scratch);
     if (c.counter) (void)hipFree(c.counter);
-    if (c.d_lt) (void)hipFree(c.d_lt);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
-    c.tables = c.pfTables = c.hcSlots = c.scratch = c.d_lt = nullptr; c.counter = nullptr; c.hcMaxBlock = 0;
-    c.ev0 = c.ev1 = nullptr; c.timed = false; c.ready = false;
+    c.tables = c.pfTables = c.hcSlots = c.scratch = nullptr; c.counter = nullptr; c.hcMaxBlock = 0;
+    c.ev0 = c.ev1 = nullptr; c.timed = false; c.laneOrderOk = true; c.ready = false;
 }
 
 int clamp_level(int level)                                       // reference lizard_compress.c:303-308
@@ -467,6 +240,10 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
     }
     int rc = ctx_init(c);
     if (rc) return rc;
+    if (!c.laneOrderOk && (lv == 10 || lv == 30 || (lv >= 13 && lv <= 17) || (lv >= 34 && lv <= 38))) {
+        snprintf(t_err, sizeof t_err, "level %d refused: device %d failed the self-check \"lanes of one LDS atomic are served in lane order\" its kernel relies on", lv, c.device);
+        return -LIZARDGPU_ERR_HARDWARE;
+    }
     LzBatch a;
     a.src = (const u8*)d_src; a.blockSize = blockSize; a.nBlocks = (u32)nBlocks; a.lastBlockSize = (u32)lastBlockSize;
     a.dst = (u8*)d_dst; a.dstStride = dstStride; a.sizes = d_sizes; a.level = (u32)lv;
@@ -853,7 +630,7 @@ int LizardGPU_residentWaves(void)
     Guard g;
     if (g.rc) return g.rc;
     int rc = ctx_init(*g.c);
-    return rc ? rc : g.c->cus * LZ_WAVES_FAST;      // level-10 residency (16 waves per CU: 12 LDS tables + 4 in global memory)
+    return rc ? rc : g.c->cus * LZ_WAVES_FAST;      // level-10 residency: 13 waves per CU, every hash table in LDS
 }
 
 void LizardGPU_shutdown(void)
@@ -1019,35 +796,6 @@ int lzgpu_compress_one(const void* src, int srcSize, void* dst, int maxDstSize, 
     LZ_HIP(hipStreamSynchronize(s.stream));
     memcpy(dst, s.h_out, csize);
     return (int)csize;
-}
-
-void LizardGPU_datagen_host(void* buffer, size_t size, double matchProba, double litProba, unsigned seed)
-{
-    uint8_t lt[LZ_RDG_LTSIZE];
-    lz_rdg_table(lt, matchProba, litProba);
-    lz_rdg_fill((uint8_t*)buffer, size, (uint32_t)(32768 * matchProba), matchProba >= 1.0, lt, seed);
-}
-
-int LizardGPU_datagen_device(void* d_dst, size_t nBlocks, size_t blockSize, double matchProba, double litProba,
-                             unsigned seed0, void* stream)
-{
-    Guard g;
-    if (g.rc) return g.rc;
-    if (!d_dst || nBlocks == 0 || blockSize == 0) { snprintf(t_err, sizeof t_err, "bad argument"); return -LIZARDGPU_ERR_ARG; }
-    Ctx& c = *g.c;
-    int rc = ctx_init(c);
-    if (rc) return rc;
-    uint8_t lt[LZ_RDG_LTSIZE];
-    lz_rdg_table(lt, matchProba, litProba);
-    if (!c.d_lt) LZ_HIP(hipMalloc((void**)&c.d_lt, LZ_RDG_LTSIZE));
-    hipStream_t s = (hipStream_t)stream;
-    LZ_HIP(hipMemcpyAsync(c.d_lt, lt, LZ_RDG_LTSIZE, hipMemcpyHostToDevice, s));
-    LZ_HIP(hipStreamSynchronize(s));                            // `lt` is a stack buffer
-    hipLaunchKernelGGL(lz_datagen_kernel, dim3((unsigned)((nBlocks + 63) / 64)), dim3(64), 0, s, (u8*)d_dst, (u64)nBlocks,
-                       (u64)blockSize, (u32)(32768 * matchProba), (int)(matchProba >= 1.0), (const u8*)c.d_lt, (u32)seed0);
-    LZ_HIP(hipGetLastError());
-    LZ_HIP(hipStreamSynchronize(s));
-    return 0;
 }
 
 #ifdef LZ_PROFILE

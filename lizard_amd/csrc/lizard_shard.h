@@ -7,17 +7,23 @@
 //   * one process, several devices : LizardGPU_compressBlocks_sharded()  (ncclCommInitAll)
 //   * one process per device       : LizardGPU_commUniqueId / _commInitRank / _gatherSizes_device — the torchrun form
 //     bench.py uses: rank 0 creates the id, the launcher's own transport carries its 128 bytes to the other ranks.
-// RCCL is loaded on first use (dlopen): single-GPU users of the library do not need it installed.
+// RCCL is resolved on first use: a copy the process has already mapped (torch's, in a torchrun job) is taken first
+// (dlopen RTLD_NOLOAD) so that a job never carries two RCCL instances on the same GPUs; only then is librccl.so.1 loaded.
+// Single-GPU users of the library do not need it installed.  The exchange itself (partition, in-place all-gather or ragged
+// broadcasts, offsets) lives in lizard_shard_core.h, written against a small collective table: RCCL fills it here,
+// LizardGPU_setCollectives swaps in another transport, and tests/shard_fake.cpp runs the same code with 2 and 3 ranks on a CPU.
 // Equal shard sizes use one ncclAllGather in place; ragged partitions (nBlocks not a multiple of the rank count)
 // one ncclBroadcast per rank inside a group.  lz_scan_kernel (lz_pack.h) turns sizes into offsets on every device.
 #pragma once
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include "lizard_shard_core.h"
 
 namespace {
 
 struct Rccl {
     void* so = nullptr;
+    bool  shared = false;                                  // resolved from a copy another library had already mapped
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
@@ -29,7 +35,7 @@ struct Rccl {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
-pthread_mutex_t g_rccl_mu = PTHREAD_MUTEX_INITIALIZER;
+pthread_mutex_t g_rccl_mu = PTHREAD_MUTEX_INITIALIZER;     // held for the whole of every call that touches a communicator
 
 // single-process communicators (one per device of the last device list) and the per-process rank communicator
 ncclComm_t g_allComms[LZ_MAX_DEVICES];
@@ -37,11 +43,18 @@ int        g_allDevs[LZ_MAX_DEVICES];
 int        g_allCount = 0;
 ncclComm_t g_rankComm = nullptr;
 int        g_rankCount = 0, g_rankIndex = -1;
+// the transport of the size exchange: RCCL unless LizardGPU_setCollectives installed another one
+LzCollectives g_userCol;
+bool          g_haveUserCol = false;
 
 int rccl_load()
 {
     if (g_rccl.so) return 0;
-    void* so = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    // a copy that is already in the process first (torchrun: torch/lib/librccl.so, soname librccl.so.1)
+    void* so = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    const bool shared = so != nullptr;
+    if (!so) so = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!so) { snprintf(t_err, sizeof t_err, "RCCL not found (dlopen librccl.so.1): %s", dlerror()); return -LIZARDGPU_ERR_RCCL; }
 #define LZ_SYM(field, name) do { *(void**)(&g_rccl.field) = dlsym(so, name); \
@@ -50,18 +63,54 @@ int rccl_load()
     LZ_SYM(CommDestroy, "ncclCommDestroy"); LZ_SYM(AllGather, "ncclAllGather"); LZ_SYM(Broadcast, "ncclBroadcast");
     LZ_SYM(GroupStart, "ncclGroupStart"); LZ_SYM(GroupEnd, "ncclGroupEnd"); LZ_SYM(GetErrorString, "ncclGetErrorString");
 #undef LZ_SYM
-    g_rccl.so = so;
+    g_rccl.so = so; g_rccl.shared = shared;
     return 0;
 }
 
-#define LZ_NCCL(call)                                                                                  \
-    do {                                                                                               \
-        ncclResult_t r_ = (call);                                                                      \
-        if (r_ != ncclSuccess) {                                                                       \
-            snprintf(t_err, sizeof t_err, "%s failed: %s", #call, g_rccl.GetErrorString(r_));          \
-            return -LIZARDGPU_ERR_RCCL;                                                                \
-        }                                                                                              \
-    } while (0)
+int nccl_fail(const char* what, ncclResult_t r)
+{
+    snprintf(t_err, sizeof t_err, "%s failed: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    return -LIZARDGPU_ERR_RCCL;
+}
+// RCCL behind the collective table of lizard_shard_core.h
+int rccl_all_gather(const void* send, void* recv, size_t count, void* comm, void* stream)
+{
+    const ncclResult_t r = g_rccl.AllGather(send, recv, count, ncclUint32, (ncclComm_t)comm, (hipStream_t)stream);
+    return r == ncclSuccess ? 0 : nccl_fail("ncclAllGather", r);
+}
+int rccl_broadcast(const void* send, void* recv, size_t count, int root, void* comm, void* stream)
+{
+    const ncclResult_t r = g_rccl.Broadcast(send, recv, count, ncclUint32, root, (ncclComm_t)comm, (hipStream_t)stream);
+    return r == ncclSuccess ? 0 : nccl_fail("ncclBroadcast", r);
+}
+int rccl_group_start() { const ncclResult_t r = g_rccl.GroupStart(); return r == ncclSuccess ? 0 : nccl_fail("ncclGroupStart", r); }
+int rccl_group_end()   { const ncclResult_t r = g_rccl.GroupEnd();   return r == ncclSuccess ? 0 : nccl_fail("ncclGroupEnd", r); }
+LzCollectives collectives()
+{
+    if (g_haveUserCol) return g_userCol;
+    LzCollectives c; c.allGather = rccl_all_gather; c.broadcast = rccl_broadcast; c.groupStart = rccl_group_start; c.groupEnd = rccl_group_end;
+    return c;
+}
+// the device-side steps around the exchange
+int hip_copy_u32(uint32_t* dst, const uint32_t* src, size_t count, void* stream)
+{
+    LZ_HIP(hipMemcpyAsync(dst, src, count * sizeof(u32), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+int hip_scan_sizes(const uint32_t* sizes, uint64_t* offsets, size_t nBlocks, void* stream)
+{
+    hipLaunchKernelGGL(lz_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const u32*)sizes, (u64*)offsets, (u32)nBlocks, 0u, 0u, LZ_PACK_PAYLOAD);
+    LZ_HIP(hipGetLastError());
+    return 0;
+}
+const LzDeviceOps kHipOps = { hip_copy_u32, hip_scan_sizes };
+
+thread_local const int* t_shardDevs = nullptr;             // device list of the sharded call in progress on this thread
+int select_shard_device(int rank)
+{
+    if (hipSetDevice(t_shardDevs[rank]) != hipSuccess) { snprintf(t_err, sizeof t_err, "hipSetDevice(%d) failed", t_shardDevs[rank]); return -LIZARDGPU_ERR_HIP; }
+    return 0;
+}
 
 void lz_shard_shutdown()
 {
@@ -74,45 +123,31 @@ void lz_shard_shutdown()
     pthread_mutex_unlock(&g_rccl_mu);
 }
 
-// Rank `rank`'s slice of the all-sizes array is already in place at all + first(rank); afterwards every rank holds
-// all of it.  Called once per rank with that rank's communicator and stream (inside a group when one process
-// drives several ranks).
-int gather_in_place(ncclComm_t comm, int nRanks, size_t nBlocks, u32* all, hipStream_t stream)
-{
-    if (nBlocks % (size_t)nRanks == 0) {
-        const size_t per = nBlocks / (size_t)nRanks;
-        // in-place form: sendbuff = recvbuff + rank * sendcount (rccl.h, ncclAllGather)
-        int rank = -1;
-        for (int r = 0; r < g_allCount; r++) if (g_allComms[r] == comm) rank = r;
-        if (comm == g_rankComm) rank = g_rankIndex;
-        LZ_NCCL(g_rccl.AllGather(all + (size_t)rank * per, all, per, ncclUint32, comm, stream));
-    } else {
-        for (int root = 0; root < nRanks; root++) {
-            size_t first, count;
-            LizardGPU_shardRange(nBlocks, root, nRanks, &first, &count);
-            if (count) LZ_NCCL(g_rccl.Broadcast(all + first, all + first, count, ncclUint32, root, comm, stream));
-        }
-    }
-    return 0;
-}
-
 }  // namespace
 
 extern "C" {
 
 void LizardGPU_shardRange(size_t nBlocks, int rank, int nRanks, size_t* first, size_t* count)
 {
-    const size_t base = nBlocks / (size_t)nRanks, rem = nBlocks % (size_t)nRanks, r = (size_t)rank;
-    if (first) *first = r * base + (r < rem ? r : rem);
-    if (count) *count = base + (r < rem ? 1 : 0);
+    lz_shard_range(nBlocks, rank, nRanks, first, count);
 }
 
 void LizardGPU_offsetsFromSizes(const uint32_t* sizes, size_t nBlocks, uint64_t* offsets)
 {
-    uint64_t run = 0;
-    for (size_t i = 0; i < nBlocks; i++) { offsets[i] = run; run += sizes[i]; }
-    offsets[nBlocks] = run;
+    lz_offsets_from_sizes(sizes, nBlocks, offsets);
 }
+
+int LizardGPU_setCollectives(const LizardGPU_Collectives* table)
+{
+    pthread_mutex_lock(&g_rccl_mu);
+    g_haveUserCol = table != nullptr;
+    if (table) { g_userCol.allGather = table->allGather; g_userCol.broadcast = table->broadcast; g_userCol.groupStart = table->groupStart; g_userCol.groupEnd = table->groupEnd; }
+    pthread_mutex_unlock(&g_rccl_mu);
+    return 0;
+}
+
+// 1 = RCCL came from a copy the process had already mapped, 0 = loaded by this library, -1 = not resolved yet
+int LizardGPU_rcclShared(void) { return g_rccl.so ? (g_rccl.shared ? 1 : 0) : -1; }
 
 int LizardGPU_compressBlocks_sharded(int nDevices, const int* devices, const void* const* d_src, size_t nBlocks,
                                      size_t blockSize, size_t lastBlockSize, void* const* d_dst, size_t dstStride,
@@ -126,57 +161,55 @@ int LizardGPU_compressBlocks_sharded(int nDevices, const int* devices, const voi
     }
     int devs[LZ_MAX_DEVICES];
     for (int r = 0; r < nDevices; r++) devs[r] = devices ? devices[r] : r;
+    int callerDev = -1;
+    if (hipGetDevice(&callerDev) != hipSuccess) { (void)hipGetLastError(); callerDev = -1; }
+    // the communicators stay locked until the exchange is enqueued: a concurrent call with another device list would destroy them
     pthread_mutex_lock(&g_rccl_mu);
-    int rc = rccl_load();
-    if (!rc) {
+    int rc = g_haveUserCol ? 0 : rccl_load();
+    if (!rc && !g_haveUserCol) {
         bool same = g_allCount == nDevices;
         for (int r = 0; same && r < nDevices; r++) same = g_allDevs[r] == devs[r];
         if (!same) {
             for (int i = 0; i < g_allCount; i++) if (g_allComms[i]) (void)g_rccl.CommDestroy(g_allComms[i]);
             g_allCount = 0;
-            ncclResult_t r_ = g_rccl.CommInitAll(g_allComms, nDevices, devs);
-            if (r_ != ncclSuccess) { snprintf(t_err, sizeof t_err, "ncclCommInitAll failed: %s", g_rccl.GetErrorString(r_)); rc = -LIZARDGPU_ERR_RCCL; }
+            const ncclResult_t r_ = g_rccl.CommInitAll(g_allComms, nDevices, devs);
+            if (r_ != ncclSuccess) rc = nccl_fail("ncclCommInitAll", r_);
             else { g_allCount = nDevices; memcpy(g_allDevs, devs, sizeof(int) * (size_t)nDevices); }
         }
     }
-    pthread_mutex_unlock(&g_rccl_mu);
-    if (rc) return rc;
     const int savedSel = t_device;
-    hipStream_t streams[LZ_MAX_DEVICES];
+    hipStream_t streams[LZ_MAX_DEVICES] = {};
+    int nLaunched = 0;                                          // ranks whose stream carries work of this call
     // 1. every device compresses its contiguous range; its sizes land in place inside its copy of the all-sizes array
     for (int r = 0; r < nDevices && !rc; r++) {
         size_t first, count;
-        LizardGPU_shardRange(nBlocks, r, nDevices, &first, &count);
+        lz_shard_range(nBlocks, r, nDevices, &first, &count);
         t_device = devs[r];
         Guard g;
         if (g.rc) { rc = g.rc; break; }
         if ((rc = ctx_init(*g.c))) break;
         streams[r] = g.c->stage[0].stream;
+        nLaunched = r + 1;
         g.c->hostKernelMs = -1.0f;
         rc = launch(*g.c, d_src[r], count, blockSize, r == nDevices - 1 ? lastBlockSize : blockSize, d_dst[r], dstStride,
                     d_allSizes[r] + first, level, streams[r]);
     }
-    // 2. the exchange: RCCL all-gather of the sizes, one rank per device, grouped
-    if (!rc) do {
-        if (g_rccl.GroupStart() != ncclSuccess) { snprintf(t_err, sizeof t_err, "ncclGroupStart failed"); rc = -LIZARDGPU_ERR_RCCL; break; }
-        for (int r = 0; r < nDevices && !rc; r++) {
-            if (hipSetDevice(devs[r]) != hipSuccess) { rc = -LIZARDGPU_ERR_HIP; break; }
-            rc = gather_in_place(g_allComms[r], nDevices, nBlocks, d_allSizes[r], streams[r]);
-        }
-        if (g_rccl.GroupEnd() != ncclSuccess && !rc) { snprintf(t_err, sizeof t_err, "ncclGroupEnd failed"); rc = -LIZARDGPU_ERR_RCCL; }
-    } while (0);
-    // 3. every device: sizes -> global output offsets
-    for (int r = 0; r < nDevices && !rc; r++) {
-        if (hipSetDevice(devs[r]) != hipSuccess) { rc = -LIZARDGPU_ERR_HIP; break; }
-        hipLaunchKernelGGL(lz_scan_kernel, dim3(1), dim3(1024), 0, streams[r], (const u32*)d_allSizes[r], (u64*)d_offsets[r], (u32)nBlocks, 0u, 0u, LZ_PACK_PAYLOAD);
-        if (hipGetLastError() != hipSuccess) { snprintf(t_err, sizeof t_err, "offset scan launch failed on device %d", devs[r]); rc = -LIZARDGPU_ERR_HIP; }
+    // 2. the exchange (one rank per device, grouped) and 3. sizes -> global output offsets on every device
+    if (!rc) {
+        void* comms[LZ_MAX_DEVICES]; void* strs[LZ_MAX_DEVICES];
+        for (int r = 0; r < nDevices; r++) { comms[r] = g_haveUserCol ? (void*)(intptr_t)r : (void*)g_allComms[r]; strs[r] = (void*)streams[r]; }
+        t_shardDevs = devs;
+        rc = lz_exchange_all(collectives(), kHipOps, nDevices, comms, nBlocks, d_allSizes, d_offsets, strs, select_shard_device);
+        t_shardDevs = nullptr;
     }
-    for (int r = 0; r < nDevices; r++) {
+    for (int r = 0; r < nLaunched; r++) {
         if (hipSetDevice(devs[r]) == hipSuccess && hipStreamSynchronize(streams[r]) != hipSuccess && !rc) {
             snprintf(t_err, sizeof t_err, "device %d: stream synchronise failed", devs[r]); rc = -LIZARDGPU_ERR_HIP;
         }
     }
+    pthread_mutex_unlock(&g_rccl_mu);
     t_device = savedSel;
+    if (callerDev >= 0) (void)hipSetDevice(callerDev);          // every entry point leaves the caller's device as it found it
     return rc;
 }
 
@@ -201,8 +234,8 @@ int LizardGPU_commInitRank(const void* id128, int nRanks, int rank)
         if (g_rankComm) { (void)g_rccl.CommDestroy(g_rankComm); g_rankComm = nullptr; }
         ncclUniqueId id;
         memcpy(&id, id128, sizeof id);
-        ncclResult_t r_ = g_rccl.CommInitRank(&g_rankComm, nRanks, id, rank);
-        if (r_ != ncclSuccess) { snprintf(t_err, sizeof t_err, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r_)); g_rankComm = nullptr; rc = -LIZARDGPU_ERR_RCCL; }
+        const ncclResult_t r_ = g_rccl.CommInitRank(&g_rankComm, nRanks, id, rank);
+        if (r_ != ncclSuccess) { g_rankComm = nullptr; rc = nccl_fail("ncclCommInitRank", r_); }
         else { g_rankCount = nRanks; g_rankIndex = rank; }
     }
     pthread_mutex_unlock(&g_rccl_mu);
@@ -213,20 +246,15 @@ int LizardGPU_gatherSizes_device(const uint32_t* d_localSizes, size_t nBlocks, u
 {
     Guard g;
     if (g.rc) return g.rc;
-    if (!g_rankComm) { snprintf(t_err, sizeof t_err, "LizardGPU_commInitRank has not been called"); return -LIZARDGPU_ERR_ARG; }
-    if (!d_localSizes || !d_allSizes || !d_offsets || nBlocks < (size_t)g_rankCount || nBlocks > 0xFFFFFFFFu) {
-        snprintf(t_err, sizeof t_err, "bad argument"); return -LIZARDGPU_ERR_ARG;
+    pthread_mutex_lock(&g_rccl_mu);
+    int rc = 0;
+    if (!g_rankComm) { snprintf(t_err, sizeof t_err, "LizardGPU_commInitRank has not been called"); rc = -LIZARDGPU_ERR_ARG; }
+    else if (!d_localSizes || !d_allSizes || !d_offsets || nBlocks < (size_t)g_rankCount || nBlocks > 0xFFFFFFFFu) {
+        snprintf(t_err, sizeof t_err, "bad argument"); rc = -LIZARDGPU_ERR_ARG;
     }
-    hipStream_t s = (hipStream_t)stream;
-    size_t first, count;
-    LizardGPU_shardRange(nBlocks, g_rankIndex, g_rankCount, &first, &count);
-    if (d_localSizes != d_allSizes + first)
-        LZ_HIP(hipMemcpyAsync(d_allSizes + first, d_localSizes, count * sizeof(u32), hipMemcpyDeviceToDevice, s));
-    int rc = gather_in_place(g_rankComm, g_rankCount, nBlocks, d_allSizes, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(lz_scan_kernel, dim3(1), dim3(1024), 0, s, (const u32*)d_allSizes, (u64*)d_offsets, (u32)nBlocks, 0u, 0u, LZ_PACK_PAYLOAD);
-    LZ_HIP(hipGetLastError());
-    return 0;
+    else rc = lz_gather_sizes(collectives(), kHipOps, (void*)g_rankComm, g_rankIndex, g_rankCount, d_localSizes, nBlocks, d_allSizes, d_offsets, stream);
+    pthread_mutex_unlock(&g_rccl_mu);
+    return rc;
 }
 
 int LizardGPU_commDestroy(void)

@@ -17,7 +17,8 @@ import util  # noqa: E402
 
 LEVELS = [10, 11, 13, 14, 15, 16, 17, 21, 22, 30, 31, 34, 35, 36, 37, 38, 41, 42]
 P50_64M_KEYS = [(10, 262144), (11, 262144), (21, 262144), (30, 262144), (10, 4 << 20), (10, 65536), (13, 262144), (15, 262144),
-                (17, 262144), (35, 262144), (22, 262144), (31, 262144), (41, 262144), (42, 262144)]
+                (17, 262144), (35, 262144), (22, 262144), (31, 262144), (41, 262144), (42, 262144),
+                (14, 262144), (16, 262144), (34, 262144), (36, 262144), (37, 262144), (38, 262144)]
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_vectors.json")
 
 

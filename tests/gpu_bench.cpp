@@ -1,7 +1,7 @@
 // tests/gpu_bench.cpp — TEST / MEASUREMENT INFRASTRUCTURE: device-resident timing of the product library through its C ABI,
 // without Python start-up.  One process = one (level, blockSize, nBlocks) configuration:
 //   gpu_bench <level> <blockSize> <nBlocks> [steps=3] [matchProbaPercent=50] [verifyBlocks=16]
-// Input: block b = RDG_genBuffer(blockSize, P, seed b), generated on the device (LizardGPU_datagen_device).
+// Input: block b = RDG_genBuffer(blockSize, P, seed b), generated on the device (tools/liblizard_datagen.so).
 // Prints the mean kernel time (HIP events inside the library), input GB/s, ratio, and checks `verifyBlocks` blocks spread
 // over the batch against the oracle (oracle/liblizard_oracle.so).  Used for tuning-variant sweeps (LD_LIBRARY_PATH picks
 // the library build) and for the rocprofv3 counter passes (scripts/gpu_traffic.sh).  Exit: 0 ok, 1 mismatch, 2 error.
@@ -13,6 +13,7 @@
 
 #include "lizard_amd.h"
 #include "lizard_oracle.h"
+extern "C" int LizardTools_datagen_device(void* d_dst, size_t nBlocks, size_t blockSize, double matchProba, double litProba, unsigned seed0, void* stream);   // tools/liblizard_datagen.so
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
 
@@ -27,7 +28,7 @@ int main(int argc, char** argv)
     const size_t stride = ((size_t)Lizard_compressBound((int)bs) + 63) & ~(size_t)63;
     unsigned char *src = nullptr, *dst = nullptr; uint32_t* sizes = nullptr;
     CK(hipMalloc((void**)&src, nb * bs)); CK(hipMalloc((void**)&dst, nb * stride)); CK(hipMalloc((void**)&sizes, nb * 4));
-    if (LizardGPU_datagen_device(src, nb, bs, P, 0.0, 0, nullptr)) { fprintf(stderr, "datagen: %s\n", LizardGPU_lastError()); return 2; }
+    if (int e = LizardTools_datagen_device(src, nb, bs, P, 0.0, 0, nullptr)) { fprintf(stderr, "datagen: hipError %d\n", e); return 2; }
     double ms = 0;
     for (int s = -1; s < steps; s++) {                       // one untimed warm-up launch
         int rc = LizardGPU_compressBlocks_device(src, nb, bs, bs, dst, stride, sizes, level, nullptr);

@@ -65,7 +65,7 @@ int main(int argc, char** argv)
 
     unsigned char* buf = malloc((size_t)nb * bs);
     double proba = argc > 4 ? atof(argv[4]) / 100.0 : 0.5;   /* datagen match probability in percent (default P50) */
-    for (int b = 0; b < nb; b++) LizardGPU_datagen_host(buf + (size_t)b * bs, bs, proba, 0.0, (unsigned)b);
+    for (int b = 0; b < nb; b++) lzo_datagen(buf + (size_t)b * bs, (size_t)bs, proba, 0.0, (unsigned)b);
 
     for (unsigned li = 0; li < sizeof levels / sizeof *levels; li++) {
         int level = levels[li];

@@ -14,6 +14,7 @@ import pytest
 import xxhash
 
 import util
+from tools import datagen as tools_datagen
 
 pytestmark = pytest.mark.gpu
 
@@ -204,8 +205,7 @@ def test_device_datagen_matches_host(L):
     import torch
     for bs, nb, p in [(262144, 70, 0.5), (4096, 300, 0.2), (65536, 65, 1.0), (1000, 64, 0.0)]:
         d = torch.empty(nb * bs, dtype=torch.uint8, device="cuda")
-        rc = L.LizardGPU_datagen_device(d.data_ptr(), nb, bs, p, 0.0, 1000, None)
-        assert rc == 0
+        tools_datagen.datagen_device(d.data_ptr(), nb, bs, p, 0.0, 1000, None)
         got = d.cpu().numpy().tobytes()
         for b in (0, 1, nb // 2, nb - 1):
             assert got[b * bs:(b + 1) * bs] == util.datagen(bs, p, 0.0, 1000 + b), (bs, b, p)
@@ -221,3 +221,37 @@ def test_lds_atomics_are_served_in_lane_order():
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "violations: 0 " in r.stdout, r.stdout + r.stderr
+
+
+def test_lane_order_self_check_refuses_dependent_levels():
+    """The library checks the lane-order property itself when a device's context is created; a device that fails is refused
+    the levels whose kernels depend on it (10/30, hashChain) with a loud error, the others keep working.  The failure branch
+    is forced through LIZARDGPU_FORCE_LANE_ORDER_FAILURE=1 in a fresh process (the check runs once per device)."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import util
+from lizard_amd import _lib
+L = _lib.lib()
+data = util.datagen(100000, 0.5, 0.0, 3)
+for level, works in ((10, False), (30, False), (15, False), (36, False), (21, True), (11, True), (42, True)):
+    out, r = util.compress_with(L.Lizard_compress, data, level)
+    if works:
+        assert out == util.oracle_compress(data, level), level
+    else:
+        assert r == 0, (level, r)
+import torch
+src = torch.zeros(4 * 65536, dtype=torch.uint8, device="cuda"); dst = torch.zeros(4 * 70000, dtype=torch.uint8, device="cuda")
+sz = torch.zeros(4, dtype=torch.int32, device="cuda")
+rc = L.LizardGPU_compressBlocks_device(src.data_ptr(), 4, 65536, 65536, dst.data_ptr(), 70000, sz.data_ptr(), 10, None)
+assert rc == -7, rc
+assert b"self-check" in L.LizardGPU_lastError(), L.LizardGPU_lastError()
+assert L.LizardGPU_compressBlocks_device(src.data_ptr(), 4, 65536, 65536, dst.data_ptr(), 70000, sz.data_ptr(), 21, None) == 0
+print("refused as expected")
+''' % (util.ROOT, os.path.join(util.ROOT, "tests"))
+    env = dict(os.environ, LIZARDGPU_FORCE_LANE_ORDER_FAILURE="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "refused as expected" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "NOT served in lane order" in r.stderr

@@ -79,3 +79,32 @@ def test_gpu_random_batches():
         outs = api.compress_blocks(data, bs, level)
         for i, o in enumerate(outs):
             assert o == util.oracle_compress(data[i * bs:(i + 1) * bs], level), (trial, level, bs, i)
+
+
+@pytest.mark.gpu
+def test_gpu_soak_time_boxed():
+    """The soak of scripts/gpu_soak.py as a driver-run test: stitched random inputs at every level, one block per call and in
+    batches, against the oracle until the time box (LIZARD_SOAK_SECONDS, default 60 s) is used up.  The seed is taken from
+    LIZARD_SOAK_SEED (default: the day number, so successive rounds walk different cases; it is printed on failure)."""
+    import os
+    import time
+    from lizard_amd import _lib, api
+    L = _lib.lib()
+    box = float(os.environ.get("LIZARD_SOAK_SECONDS", "60"))
+    seed = int(os.environ.get("LIZARD_SOAK_SEED", str(int(time.time()) // 86400)))
+    rng = random.Random(seed)
+    t0, n = time.time(), 0
+    while time.time() - t0 < box:
+        for _ in range(40):
+            data = make_case(rng, 500000)
+            level = rng.choice(LEVELS)
+            out, r = util.compress_with(L.Lizard_compress, data, level)
+            assert out == util.oracle_compress(data, level), ("one block", seed, n, level, len(data))
+            n += 1
+        level = rng.choice(LEVELS); bs = rng.choice([1000, 4096, 30000, 65536, 131072, 262144, 400000])
+        data = b"".join(make_case(rng, 300000) for _ in range(40))
+        for i, o in enumerate(api.compress_blocks(data, bs, level)):
+            assert o == util.oracle_compress(data[i * bs:(i + 1) * bs], level), ("batch", seed, n, level, bs, i)
+            n += 1
+    print(f"soak: seed {seed}, {n} cases in {time.time() - t0:.0f} s, 0 mismatches")
+    assert n > 100

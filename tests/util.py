@@ -10,6 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 REF_DIR = os.path.join(ORACLE_DIR, "_ref")
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+import sys
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 _c = ctypes
 _COMPRESS_SIG = [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int]

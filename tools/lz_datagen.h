@@ -1,4 +1,4 @@
-// lz_datagen.h — deterministic synthetic-input generator used by the benchmark and the tests.
+// tools/lz_datagen.h — deterministic synthetic-input generator used by the benchmark and the tests (tooling, not in the product library).
 //
 // Restates the *behaviour* of the reference's data generator (programs/datagen.c:59-160,
 // RDG_genBuffer / RDG_genBlock with prefixSize 0) so that measurements run on exactly the byte
