@@ -682,10 +682,10 @@ LZ_DEV u32 lz_write_subblock_seq(const u8* src, u32 S, u32 E, u8* op, LzStreams&
 // seqRing:  LZ_SEQ_RING u64 of LDS.
 // tabKind / tableMem — where and how this wave keeps its hash table:
 //   LZ_TABKIND_LDS     fast parser: LZ_TAB_BYTES(HASHLOG) bytes of LDS (24-bit slots with check bits, LzTab);
-//                      priceFast: the same size, 24-bit positions (LzTabPf24, blocks < 16 MiB)
+//                      priceFast: 4 << HASHLOG bytes of LDS, u32 slots = 24-bit position + 8 check bits (LzTab32L, blocks < 16 MiB)
 //   LZ_TABKIND_GLOBAL  u32 slots in global memory: fast parser LZ_TABWIDE_BYTES(HASHLOG) bytes, 16-byte aligned
-//                      (LzTabWide, blocks <= 4 MiB; the only form for HASHLOG > 14); priceFast 4 << HASHLOG bytes (LzTab32)
-//   LZ_TABKIND_LDS18   priceFast only: LZ_TAB18_BYTES(HASHLOG) bytes of LDS, 18-bit positions (LzTab18, blocks <= 256 KiB)
+//                      (LzTabWide, blocks <= 4 MiB; the only form for HASHLOG > 14); priceFast 4 << HASHLOG bytes (LzTab32G)
+//   LZ_TABKIND_LDS18   priceFast only: LZ_TAB24C_BYTES(HASHLOG) bytes of LDS, 18-bit position + 6 check bits (LzTab24c, blocks <= 256 KiB)
 // AUX:      priceFast -> TAGLOG of the round tag array (ws holds 2^TAGLOG bytes of LDS).
 //           hashChain -> searchLength (4 or 5); tableMem = the wave's LZ_HC_SLOT_BYTES slot (global, zeroed once by
 //           the host), ws doubles as the 2^LZ_HC_TAGLOG-byte tag array.
@@ -714,10 +714,11 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
     LzTab tab = lz_tab_bind<kWide ? 1 : HASHLOG>(tableMem);
     LzTabWide tabw; tabw.w = (u32*)tableMem; tabw.tag = ws; tabw.tagMask = (1u << wideTagLog) - 1u;
     if constexpr (PARSER == LZ_PARSER_FAST && HASHLOG > 14) { tabw.occ = wideOcc; tabw.occShift = wideOcc ? (u32)HASHLOG - wideOccLog : 0u; }
-    LzTabPf24 pf24; pf24.lo = tab.lo; pf24.hi = tab.hi;
-    LzTab32 pf32; pf32.w = (u32*)tableMem;
-    if constexpr (PARSER == LZ_PARSER_PRICEFAST && HASHLOG > 14) { pf32.occ = wideOcc; pf32.occShift = wideOcc ? (u32)HASHLOG - wideOccLog : 0u; }
-    LzTab18 pf18; pf18.lo = (u16*)tableMem; pf18.hi = (u32*)((u8*)tableMem + (2u << (kWide ? 1 : HASHLOG)));
+    // priceFast table forms (lz_pricefast.h): u32 slots in global memory / in LDS, or the packed 18 + 6 bit LDS form
+    LzTab32G pf32g; pf32g.w = (u32*)tableMem;
+    if constexpr (PARSER == LZ_PARSER_PRICEFAST && HASHLOG > 14) { pf32g.occ = wideOcc; pf32g.occShift = wideOcc ? (u32)HASHLOG - wideOccLog : 0u; }
+    LzTab32L pf32l; pf32l.w = (u32*)tableMem; pf32l.lds = true;
+    LzTab24c pf24c; pf24c.lo = (u16*)tableMem; pf24c.hi = (u8*)tableMem + (2u << (kWide ? 1 : HASHLOG));
     LzHc hc;
     if constexpr (PARSER == LZ_PARSER_HASHCHAIN) {
         const u32 row = (level >= 30u ? level - 21u : level) - 13u;                  // lizard_common.h:240-244, :264-268
@@ -730,9 +731,9 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
         if (tabKind == LZ_TABKIND_GLOBAL) lz_tab_fresh<HASHLOG>(tabw);
         else { lz_tab_fresh<HASHLOG>(tab); st.sweepAt = 32768u; }
     }
-    else if (tabKind == LZ_TABKIND_GLOBAL) lz_pf_tab_fresh<HASHLOG>(pf32);
-    else if (tabKind == LZ_TABKIND_LDS18)  lz_pf_tab_fresh<HASHLOG>(pf18);
-    else                                   lz_pf_tab_fresh<HASHLOG>(pf24);
+    else if (tabKind == LZ_TABKIND_GLOBAL) lz_pf_tab_fresh<HASHLOG>(pf32g);
+    else if (tabKind == LZ_TABKIND_LDS18)  lz_pf_tab_fresh<HASHLOG>(pf24c);
+    else                                   lz_pf_tab_fresh<HASHLOG>(pf32l);
     lz_wave_sync();
     LZ_PROF(st, 6);                                           // table init
     if (lane == 0) dst[0] = (u8)level;                        // lizard_compress.c:488
@@ -748,9 +749,9 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
             if (tabKind == LZ_TABKIND_GLOBAL) lz_parse_fast<HASHLOG>(src, pos, pos + part, tabw, st);
             else                              lz_parse_fast<HASHLOG>(src, pos, pos + part, tab, st);
         }
-        else if (tabKind == LZ_TABKIND_GLOBAL) lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, pf32, ws, st);
-        else if (tabKind == LZ_TABKIND_LDS18)  lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, pf18, ws, st);
-        else                                   lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, pf24, ws, st);
+        else if (tabKind == LZ_TABKIND_GLOBAL) lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, pf32g, ws, st);
+        else if (tabKind == LZ_TABKIND_LDS18)  lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, pf24c, ws, st);
+        else                                   lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, pf32l, ws, st);
         {   // Huffman workspace: the wave's own (it doubles as the parser's tag array), or one borrowed from the workgroup's pool
             LzHufPool pool; pool.base = hufPoolMask ? hufPoolBase : (u32*)ws; pool.mask = hufPoolMask; pool.count = hufPoolCount; pool.stride = LZ_HUF_WS_WORDS;
             op += lz_write_subblock_seq<HUF, kLiz>(src, pos, pos + part, dst + op, st, pool);

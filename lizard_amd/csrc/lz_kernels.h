@@ -66,7 +66,7 @@ template <int PARSER, int HASHLOG, int AUX, bool HUF, int W, int WSWORDS, int NL
 __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
 {
     struct Slice { u64 ring[LZ_SEQ_RING]; u32 ws[WSWORDS]; };
-    constexpr u32 kTabWords = (LDSKIND == LZ_TABKIND_LDS18 ? LZ_TAB18_BYTES(HASHLOG) : LZ_TAB_BYTES(HASHLOG)) / 4u + 1u;
+    constexpr u32 kTabWords = (LDSKIND == LZ_TABKIND_LDS18 ? LZ_TAB24C_BYTES(HASHLOG) : PARSER == LZ_PARSER_PRICEFAST ? (4u << HASHLOG) : LZ_TAB_BYTES(HASHLOG)) / 4u + 1u;
     __shared__ u32 ldsTables[NLDS ? NLDS : 1][NLDS ? kTabWords : 1];
     __shared__ Slice lds[W];
     // mixed residency: only the global-table waves need a round tag array (LzTabWide / LzTab32; the LDS-table waves find

@@ -20,11 +20,18 @@
 // before any output exists; lz_encode_lizv1 then writes tokens, literals and both offset streams 64
 // sequences per step straight into their final place in dst (staging only in front of the Huffman stage).
 //
-// Memory latency structure of a round: the 8 source bytes of every lane and its repeat-offset candidate are
-// requested together (both addresses are known before the table is read); the hash candidate follows the
-// LDS (or global) table read.  All loads are unconditional with clamped addresses, so no exec-masked load
-// forces an early vmcnt(0).
-//
+// Memory latency structure (round 3): ONE exposed memory trip per sequence.
+//   * Every table form carries check bits (a hash of the 4 bytes at the stored position) beside the position: a candidate whose
+//     check differs from the probing position's cannot pass the reference's 4-byte test (pricefast.h:67 / :109) and is never
+//     fetched — with hashLog 14 a 256 KiB block puts 16 positions into every bucket, so nearly every probe finds a false one.
+//   * The lanes whose hash candidate survives fetch, in ONE batch together with the repeat-offset candidate of every lane
+//     (contiguous, so a line or two per load), everything the winner needs: 24 bytes forward at candidate and position and 8
+//     backward — the 4-byte tests, the long-offset length rule (:69), the winner's forward length (< 24) and its backward
+//     extension (< 8) all come out of that one trip.
+//   * The source bytes of the round live in a register window of 128 positions (A: position ip + lane, B: ip + 64 + lane, 8
+//     bytes each).  The next round starts at most 64 positions further in the common case, so its bytes are a lane shift of
+//     the window (ds_bpermute) and only the far half is requested from memory — one round ahead of its use.  The lazy step's
+//     probe position (ip + ml - 2) is read out of the same window, and its candidate is fetched only if its check bits agree.
 // Included from lz_block.h after the shared helpers.
 #pragma once
 
@@ -34,58 +41,41 @@
 // ---- hash tables of the priceFast levels (ours; only the parse RESULT is pinned by the reference) ----
 // All hold block-relative positions; kEmpty is a value no probe position reaches, so an empty slot fails
 // "e < p" like the reference's zeroed slot fails "e >= lowLimit" and is always overwritten (:170-171).
-//   LzTab   (lz_block.h)  u16 + u8 arrays, 24-bit positions: blocks < 16 MiB, 48 KiB of LDS at hashLog 14
-//   LzTab18               u16 array + 2 bits per slot packed 16 to a dword (ds_mskor): 18-bit positions, i.e.
-//                         blocks <= 256 KiB — the benchmark configuration — in 36 KiB: four tables per CU instead
-//                         of three (the waves whose table is in LDS are ~5x faster than the others)
-//   LzTab32               u32 slots in global memory (one sector per access): 24-bit position + 8 check bits
+// Every form carries check bits beside the position (a hash of the 4 bytes there).
+//   LzTab24c  LDS, u16 + u8 arrays: 18-bit position + 6 check bits, blocks <= 256 KiB — the benchmark configuration —
+//             48 KiB at hashLog 14: three tables per CU
+//   LzTab32   u32 slots, 24-bit position + 8 check bits, blocks < 16 MiB: in LDS (64 KiB at hashLog 14, two per CU) for
+//             the larger blocks, in a global-memory slot (one sector per access) for the waves without an LDS table and
+//             for hashLog 18 (levels 22/42)
 #define LZ_EMPTY24 0xFFFFFFu
 #define LZ_EMPTY18 0x3FFFFu
-struct LzTabPf24 {
+struct LzTab24c {
     u16* lo; u8* hi;
-    static constexpr u32 kEmpty = LZ_EMPTY24;
+    static constexpr u32 kEmpty = LZ_EMPTY18;
     static constexpr bool kSpecPut = true;
-    static constexpr bool kCheck = false;                        // no room for check bits beside the position
-    LZ_DEVM static u32 pos(u32 raw) { return raw; }
-    LZ_DEVM static u32 chk(u32) { return 0u; }
-    LZ_DEVM static u32 make(u32 p, u32) { return p; }
+    static constexpr bool kLds = true;
+    LZ_DEVM static u32 pos(u32 raw) { return raw & 0x3FFFFu; }
+    LZ_DEVM static u32 chk(u32 raw) { return raw >> 18; }
+    LZ_DEVM static u32 chkOf(u32 first4) { return (first4 * 2654435761u) >> 26; }
+    LZ_DEVM static u32 make(u32 p, u32 c) { return p | (c << 18); }
     LZ_DEVM void specPut(u32 h, u32 p) const { lo[h] = (u16)p; }
     LZ_DEVM bool specLost(u32 h, u32 p) const { return lo[h] != (u16)p; }
     LZ_DEVM u32  get(u32 h) const { return (u32)lo[h] | ((u32)hi[h] << 16); }
     LZ_DEVM void set(u32 h, u32 v) const { lo[h] = (u16)v; hi[h] = (u8)(v >> 16); }
     LZ_DEVM void sync() const { lz_lds_sync(); }
 };
-struct LzTab18 {
-    u16* lo; u32* hi;
-    static constexpr u32 kEmpty = LZ_EMPTY18;
-    static constexpr bool kSpecPut = true;
-    static constexpr bool kCheck = false;
-    LZ_DEVM static u32 pos(u32 raw) { return raw; }
-    LZ_DEVM static u32 chk(u32) { return 0u; }
-    LZ_DEVM static u32 make(u32 p, u32) { return p; }
-    LZ_DEVM void specPut(u32 h, u32 p) const { lo[h] = (u16)p; }
-    LZ_DEVM bool specLost(u32 h, u32 p) const { return lo[h] != (u16)p; }
-    LZ_DEVM u32  get(u32 h) const { return (u32)lo[h] | (((hi[h >> 4] >> (2u * (h & 15u))) & 3u) << 16); }
-    LZ_DEVM void set(u32 h, u32 v) const { lo[h] = (u16)v; lz_lds_mskor(&hi[h >> 4], 3u << (2u * (h & 15u)), (v >> 16) << (2u * (h & 15u))); }
-    LZ_DEVM void sync() const { lz_lds_sync(); }
-};
-#define LZ_TAB18_BYTES(HASHLOG) ((2u << (HASHLOG)) + ((1u << (HASHLOG)) >> 2))
+#define LZ_TAB24C_BYTES(HASHLOG) (3u << (HASHLOG))
 struct LzTab32 {
     u32* w;
+    bool lds = false;                                            // the slots are in LDS (speculative put + read-back finds same-slot lanes)
     static constexpr u32 kEmpty = LZ_EMPTY24;
-    static constexpr bool kSpecPut = false;
-    // The upper byte of a slot is a check hash of the 4 bytes at the stored position: a candidate whose check differs from
-    // the probing position's cannot pass the reference's 4-byte test (pricefast.h:67 / :109), so its bytes — a random
-    // 128-byte line of the block — are never fetched.
-    static constexpr bool kCheck = true;
     LZ_DEVM static u32 pos(u32 raw) { return raw & 0xFFFFFFu; }
     LZ_DEVM static u32 chk(u32 raw) { return raw >> 24; }
+    LZ_DEVM static u32 chkOf(u32 first4) { return (first4 * 2654435761u) >> 24; }
     LZ_DEVM static u32 make(u32 p, u32 c) { return p | (c << 24); }
     // Occupancy summary (LDS, optional; levels 22/42 with their 2^18 slots): as LzTabWide::occ in lz_block.h
     u32* occ = nullptr;
     u32 occShift = 0;
-    LZ_DEVM void specPut(u32, u32) const {}
-    LZ_DEVM bool specLost(u32, u32) const { return false; }
     LZ_DEVM u32  get(u32 h) const
     {
         if (!occ) return w[h];
@@ -99,18 +89,32 @@ struct LzTab32 {
         w[h] = v;
         if (occ) { const u32 b = h >> occShift; lz_lds_atomic_or(&occ[b >> 5], 1u << (b & 31u)); }
     }
+};
+// the two residences of LzTab32 as types (the parser is compiled once per form)
+struct LzTab32G : LzTab32 {
+    static constexpr bool kSpecPut = false;
+    static constexpr bool kLds = false;
+    LZ_DEVM void specPut(u32, u32) const {}
+    LZ_DEVM bool specLost(u32, u32) const { return false; }
     LZ_DEVM void sync() const { lz_wave_sync(); }
 };
-template <int HASHLOG> LZ_DEV void lz_pf_tab_fresh(const LzTabPf24& t) { for (u32 i = lz_lane(); i < (1u << HASHLOG); i += 64u) t.set(i, LZ_EMPTY24); }
+struct LzTab32L : LzTab32 {
+    static constexpr bool kSpecPut = true;
+    static constexpr bool kLds = true;
+    // speculative put of the low half only: the position's low 16 bits tell the lanes of a round apart (they differ by < 64)
+    LZ_DEVM void specPut(u32 h, u32 p) const { ((u16*)w)[2u * h] = (u16)p; }
+    LZ_DEVM bool specLost(u32 h, u32 p) const { return ((u16*)w)[2u * h] != (u16)p; }
+    LZ_DEVM void sync() const { lz_lds_sync(); }
+};
 template <int HASHLOG> LZ_DEV void lz_pf_tab_fresh(const LzTab32& t)
 {
     for (u32 i = lz_lane(); i < (1u << HASHLOG); i += 64u) t.w[i] = LZ_EMPTY24;
     if (t.occ) for (u32 i = lz_lane(); i < (((1u << HASHLOG) >> t.occShift) >> 5); i += 64u) t.occ[i] = 0u;
 }
-template <int HASHLOG> LZ_DEV void lz_pf_tab_fresh(const LzTab18& t)
+template <int HASHLOG> LZ_DEV void lz_pf_tab_fresh(const LzTab24c& t)
 {
     for (u32 i = lz_lane(); i < (1u << HASHLOG) / 2u; i += 64u) ((u32*)t.lo)[i] = 0xFFFFFFFFu;
-    for (u32 i = lz_lane(); i < (1u << HASHLOG) / 16u; i += 64u) t.hi[i] = 0xFFFFFFFFu;
+    for (u32 i = lz_lane(); i < (1u << HASHLOG) / 4u; i += 64u) ((u32*)t.hi)[i] = 0x03030303u;     // position bits 16-17 set, check bits 0
 }
 
 // ---- sequence list (LIZv1): L < 2^18, ml < 2^18, off < 2^24 (0 = repeat the last offset) ----
@@ -192,8 +196,9 @@ LZ_DEV void lz_encode_lizv1(const u8* src, u32 S, const LzStreams& st, u8* litOu
 }
 
 // Sub-block [S,E) of the block at src. windowLog 22 / minMatchLongOff 16 are the level-21/22 values
-// (lizard_common.h:249-250).  table: 2^HASHLOG positions (TAB::kEmpty = never written); tag: 2^TAGLOG bytes of LDS.
+// (lizard_common.h:249-250).  table: 2^HASHLOG slots (TAB::kEmpty = never written); tag: 2^TAGLOG bytes of LDS (global tables only).
 // Positions must stay below TAB::kEmpty (the launcher picks the table form by block size).
+#define LZ_PF_UNRESOLVED 0xFFFFu
 template <int HASHLOG, int TAGLOG, class TAB>
 LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8* tag, LzStreams& st)
 {
@@ -207,28 +212,39 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
     if (E - S < LZ_MFLIMIT + 1u) { st.lastLits = E - S; st.nlit += E - S; return; }
     const u32 mflimit = E - LZ_MFLIMIT, matchlimit = E - LZ_LASTLITERALS;
     u32 ip = S + 1u;                                             // uniform, pricefast.h:155
-    // First round after a sequence: its loads are issued as soon as the sequence's forward length is known, for the
-    // position the parse continues at if the lazy step does not find a second match (the common case); checked at use.
-    bool havePre = false;                                        // uniform
-    u32 preIp = 0, preOff = 0;                                   // uniform: the prediction
-    u64 preBytes = 0; u32 preRep4 = 0;
+    // Register window over the source: wA = the 8 bytes at winBase + lane, wB = at winBase + 64 + lane (positions from mflimit
+    // on are never probed; their lanes hold the bytes at S).  A round probes winBase + lane, i.e. wA.
+    u32 winBase = ip;                                            // uniform
+    u64 wA, wB;
+    { const u32 qa = ip + lane, qb = ip + 64u + lane; wA = lz_ld64(src + (qa < mflimit ? qa : S)); wB = lz_ld64(src + (qb < mflimit ? qb : S)); }
     for (;;) {
         // ---------------- search: 64 consecutive positions per round ----------------
-        u32 P = 0, M = 0;
+        u32 P = 0, M = 0, ml = 0, back0 = 0;
         for (;;) {
             if (ip >= mflimit) goto tail;                        // pricefast.h:158
+            // move the window to ip: up to 64 positions further its near half is a lane shift of what is already here and only the
+            // far half is requested (it is used a round from now: by the lazy step, or as the next round's near half)
+            if (ip != winBase) {
+                const u32 d = ip - winBase;                      // uniform
+                const u32 qa = ip + lane, qb = ip + 64u + lane;
+                if (d == 64u) wA = wB;
+                else if (d < 64u) {
+                    const u32 sl = (d + lane) & 63u;
+                    const u32 al = lz_shfl((u32)wA, sl), ah = lz_shfl((u32)(wA >> 32), sl);
+                    const u32 bl = lz_shfl((u32)wB, sl), bh = lz_shfl((u32)(wB >> 32), sl);
+                    wA = d + lane < 64u ? ((u64)al | ((u64)ah << 32)) : ((u64)bl | ((u64)bh << 32));
+                }
+                else wA = lz_ld64(src + (qa < mflimit ? qa : S));
+                wB = lz_ld64(src + (qb < mflimit ? qb : S));
+                winBase = ip;
+            }
             const u32 p = ip + lane;
             const bool valid = p < mflimit;
             const u32 lowPos = p > maxDist ? p - maxDist : 0u;   // pricefast.h:11-13, per probe
-            // source bytes and the repeat-offset candidate: both addresses are known up front
-            const bool repCand = valid && last_off >= LZ_MIN_OFFSET && p >= last_off && p - last_off >= lowPos;   // :19
-            u64 bytes; u32 rep4;
-            if (havePre && ip == preIp && last_off == preOff) { bytes = preBytes; rep4 = preRep4; }
-            else { bytes = lz_ld64(src + (valid ? p : S)); rep4 = lz_ld32(src + (repCand ? p - last_off : S)); }
-            havePre = false;
+            const u64 bytes = wA;
             const u32 first4 = (u32)bytes;
             const u32 h = lz_hash5<HASHLOG>(bytes);
-            const u32 myChk = TAB::kCheck ? (first4 * 2654435761u) >> 24 : 0u;
+            const u32 myChk = TAB::chkOf(first4);
             u32 e, ec;                                           // pricefast.h:160,168 (old value; garbage when !valid); its check bits
             { const u32 raw = table.get(h); e = TAB::pos(raw); ec = TAB::chk(raw); }
             // Which lanes of this round share a table slot?  LDS tables: every lane stores the low half of its position
@@ -248,7 +264,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
                 lost = valid && tag[h & tagMask] != (u8)lane;
                 lz_lds_sync();                                   // tag reads done before the next round's writes
             }
-            LZ_PROF(st, 8);                                      // (instrumented build) round: source + repeat bytes, hash, table read
+            LZ_PROF(st, 8);                                      // (instrumented build) round: window, hash, table read
             const u32 eOld = e, ecOld = ec;
             u64 pend = lz_ballot(lost);
             u64 grp = laneBit;
@@ -260,10 +276,10 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
                 const bool mine = valid && h == hv;
                 const u64 g = lz_ballot(mine);
                 u32 t = lz_readlane(e, f);                       // slot value before this round (uniform)
-                u32 tc = TAB::kCheck ? lz_readlane(ec, f) : 0u;  // ... and its check bits
+                u32 tc = lz_readlane(ec, f);                     // ... and its check bits
                 for (u64 m = g; m; m &= m - 1ull) {
                     const u32 k = lz_ctz64(m), pk = ip + k;
-                    const u32 ck = TAB::kCheck ? lz_readlane(myChk, k) : 0u;
+                    const u32 ck = lz_readlane(myChk, k);
                     if (lane == k) { e = t; ec = tc; }
                     const bool put = t >= pk || pk >= t + LZ_MIN_OFFSET;
                     t = put ? pk : t; tc = put ? ck : tc;
@@ -273,18 +289,41 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
                 pend &= ~g;
             }
             LZ_PROF(st, 9);                                      // round: same-slot replay
-            // Lizard_FindMatchFast, pricefast.h:3-87: the repeat offset wins and hides the hash candidate
-            const bool hashCand = valid && e < p && e >= lowPos && p - e >= LZ_MIN_OFFSET                   // :63-65
-                                  && (!TAB::kCheck || ec == myChk);                                         // differing check bits: the 4-byte test (:67) would fail
-            const u32 c4 = lz_ld32(src + (hashCand ? e : S));
-            const bool rep = repCand && rep4 == first4;                                                     // :19-31
-            bool hashOk = !rep && hashCand && c4 == first4;                                                 // :67
-            const bool needLong = hashOk && p - e >= LZ_16BIT_OFFSET;                                       // :69: needs ml >= minMatchLongOff
-            if (lz_ballot(needLong)) {
-                if (needLong) hashOk = p + 16u <= matchlimit && lz_ld32(src + p + 4) == lz_ld32(src + e + 4)
-                                    && lz_ld64(src + p + 8) == lz_ld64(src + e + 8);
-                lz_converge();
+            // Lizard_FindMatchFast, pricefast.h:3-87.  Candidates: the repeat offset (:19; it wins and hides the hash candidate) and
+            // the hash candidate (:63-65) if its check bits agree (else the 4-byte test of :67 fails).  One batch of loads serves
+            // both: the repeat candidates of the 64 lanes are contiguous, the hash candidates are few.
+            const bool repCand = valid && last_off >= LZ_MIN_OFFSET && p >= last_off && p - last_off >= lowPos;
+            const bool hashCand = valid && e < p && e >= lowPos && p - e >= LZ_MIN_OFFSET && ec == myChk;
+            const bool have24 = p + 24u <= E;                    // third 8 bytes readable inside the sub-block (p + 16 <= E - 5 always)
+            const u32 fc = have24 ? 16u : 0u;
+            const u32 pp = valid ? p : S, rp = repCand ? p - last_off : S;
+            const u64 rA = lz_ld64(src + rp), rB = lz_ld64(src + rp + 8u), rC = lz_ld64(src + rp + fc);
+            const u64 pB = lz_ld64(src + pp + 8u), pC = lz_ld64(src + pp + fc);
+            u64 cA = 0, cB = 0, cC = 0, cZ = 0, pZ = 0;
+            const bool haveBack = hashCand && e >= 8u;           // then p >= 16 as well
+            if (hashCand) {                                      // one batch, straight-line
+                const u32 zb = haveBack ? 8u : 0u;
+                cA = lz_ld64(src + e); cB = lz_ld64(src + e + 8u); cC = lz_ld64(src + e + fc);
+                cZ = lz_ld64(src + (e - zb)); pZ = lz_ld64(src + (p - zb));
             }
+            lz_converge();
+            const bool rep = repCand && (u32)rA == first4;                                                  // :19-31
+            u32 fwd = LZ_PF_UNRESOLVED, bwd = LZ_PF_UNRESOLVED;  // exact when the difference (or the limit) lies inside the fetched bytes
+            bool hashOk;
+            {
+                const u64 x = bytes ^ (rep ? rA : cA), y = pB ^ (rep ? rB : cB), y2 = pC ^ (rep ? rC : cC), z = pZ ^ cZ;
+                const u32 seen = have24 ? 24u : 16u;
+                const u32 common = x ? lz_ctz64(x) >> 3 : y ? 8u + (lz_ctz64(y) >> 3) : (have24 && y2) ? 16u + (lz_ctz64(y2) >> 3) : seen;
+                const u32 room = matchlimit - p;                 // p < matchlimit for every valid slot
+                if (common < seen || room <= seen) fwd = common < room ? common : room;
+                // :67 the 4-byte test, :69 a long offset needs ml >= minMatchLongOff (16 <= 24 fetched bytes: decided here)
+                hashOk = !rep && hashCand && (u32)cA == first4
+                      && (p - e < LZ_16BIT_OFFSET || (have24 && common >= LZ_MM_LONGOFF && room >= LZ_MM_LONGOFF));
+                const u32 roomB = (p - anchor) < e ? (p - anchor) : e;                                      // :176-180
+                const u32 cb = !haveBack ? 0u : z ? lz_clz64(z) >> 3 : 8u;
+                if (roomB <= cb || (haveBack && cb < 8u)) bwd = cb < roomB ? cb : roomB;
+            }
+            lz_pin(fwd); lz_pin(bwd);                            // computed here, under this batch's counted wait
             const u64 okMask = lz_ballot(rep || hashOk);
             const u64 validMask = lz_ballot(valid);
             LZ_PROF(st, 10);                                     // round: candidate bytes, tests
@@ -305,6 +344,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
             if (okMask) {
                 P = lz_readlane(p, w);
                 M = lz_readlane(rep ? p - last_off : e, w);
+                ml = lz_readlane(fwd, w); back0 = lz_readlane(bwd, w);
                 break;
             }
             ip += lz_popc64(validMask);                          // "ip++" for every probed position, :173
@@ -312,51 +352,28 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
         // ---------------- winner: lengths, lazy re-search, sequence push ----------------
         LZ_PROF(st, 0);                                          // search rounds
         {
-            u32 ml, back0;
-            // The lazy step will look at start2 = P + (forward length) - 2 (:187).  The forward length is not known yet, but
-            // it is usually short: lane j prepares the lookup for length 4 + j — source bytes, hash, table slot — while the
-            // winner's own lengths are being measured, so that the lazy step starts with its candidate already in hand.
-            // (The table is in its final state for this round: the lookup of :188 happens after the puts of :170-171.)
-            // Only where a table read is an LDS access: in global memory 64 speculative slots per sequence are 64 more sectors.
-            constexpr bool kSpecLazy = TAB::kSpecPut;
-            const u32 qSpec = P + 2u + lane;
-            u64 bSpec = 0;
-            if constexpr (kSpecLazy) bSpec = lz_ld64(src + (qSpec + 8u <= E ? qSpec : S));
-            lz_count_both(src, P, M, matchlimit, anchor, ml, back0);                      // both lengths, one round trip
-            u32 hSpec = 0, eSpec = 0;
-            if constexpr (kSpecLazy) { hSpec = lz_hash5<HASHLOG>(bSpec); eSpec = table.get(hSpec); }
-            {   // loads of the next round, should the parse continue right behind this match with this offset
-                const u32 offP = P - M;                          // (a repeat match leaves last_off as it is: P - M == last_off then)
-                preIp = P + ml; preOff = offP;
-                const u32 pp = preIp + lane;
-                const bool pv = pp < mflimit;
-                const u32 plow = pp > maxDist ? pp - maxDist : 0u;
-                const bool prc = pv && offP >= LZ_MIN_OFFSET && pp >= offP && pp - offP >= plow;
-                preBytes = lz_ld64(src + (pv ? pp : S));
-                preRep4 = lz_ld32(src + (prc ? pp - offP : S));
-                havePre = true;
-            }
-            const u32 specIdx = ml - 4u;                                                  // lane that guessed right (if < 64)
-            bool useSpec = kSpecLazy && specIdx < 64u && P + ml - 2u + 8u <= E;
+            if (ml == LZ_PF_UNRESOLVED) ml = 24u + lz_count_fwd(src, P + 24u, M + 24u, matchlimit);   // (unresolved: 24 bytes were seen and agree)
             u32 ml2 = 0, start2 = 0, ref2 = 0, ref = M, back2 = 0;
             ip = P;
             if (ip - ref == last_off) { ref = ip; goto encode; }                          // :174 -> repeat offset, no lazy step
+            if (back0 == LZ_PF_UNRESOLVED) back0 = lz_count_back(src, P, M, anchor);
             ip -= back0; ref -= back0; ml += back0;                                       // :176-182
         search:
             LZ_PROF(st, 2);                                      // winner lengths / arbitration
             if (ip + ml >= mflimit) goto encode;                                          // :185
             start2 = ip + ml - 2u;
             {
-                u32 h2, e2, c2 = 0, chk2 = 0;
-                if (useSpec) { h2 = lz_readlane(hSpec, specIdx); e2 = lz_readlane(eSpec, specIdx); }
-                else {
-                    const u64 b2 = lz_ld64(src + start2);
-                    h2 = lz_hash5<HASHLOG>(b2);
-                    const u32 raw2 = table.get(h2);
-                    e2 = TAB::pos(raw2); c2 = TAB::chk(raw2);
-                    chk2 = TAB::kCheck ? ((u32)b2 * 2654435761u) >> 24 : 0u;
-                }
-                useSpec = false;                                                          // later passes look elsewhere
+                // the 8 bytes at start2: out of the register window when it reaches that far (start2 < mflimit - 2 here)
+                const u32 i2 = start2 - winBase;                 // uniform
+                u64 b2;
+                if (i2 < 128u) {
+                    const u32 lo = i2 < 64u ? lz_readlane((u32)wA, i2 & 63u) : lz_readlane((u32)wB, i2 & 63u);
+                    const u32 hi = i2 < 64u ? lz_readlane((u32)(wA >> 32), i2 & 63u) : lz_readlane((u32)(wB >> 32), i2 & 63u);
+                    b2 = (u64)lo | ((u64)hi << 32);
+                } else b2 = lz_ld64(src + start2);
+                const u32 h2 = lz_hash5<HASHLOG>(b2);
+                const u32 raw2 = table.get(h2);
+                const u32 e2 = TAB::pos(raw2), c2 = TAB::chk(raw2), chk2 = TAB::chkOf((u32)b2);
                 const u32 low2 = start2 > maxDist ? start2 - maxDist : 0u;
                 ml2 = 0; back2 = 0;
                 if (e2 < start2 && e2 >= low2 && start2 - e2 >= LZ_MIN_OFFSET && c2 == chk2) {              // :106-110 (check bits differ: :109 fails)
