@@ -254,7 +254,9 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
     const bool pfSmall = blockSize <= (256u << 10);                         // 18-bit LDS tables
     const bool huf = lv >= 30;
     u32 W;
-    if (lv == 10 || lv == 30)      W = fastMixed ? (huf ? LZ_WAVES_FAST_HUF : LZ_WAVES_FAST) : (huf ? LZ_WAVES_FASTLDS_HUF : LZ_WAVES_FASTLDS);
+    u32 perGroup = 0;                                                        // blocks in flight per workgroup when that is not W (producer / consumer form)
+    if ((lv == 10 || lv == 30) && LZ_FAST12_SPLIT) { W = huf ? LZ_SPLIT_PROD_HUF + LZ_SPLIT_CONS_HUF : LZ_SPLIT_PROD + LZ_SPLIT_CONS; perGroup = huf ? LZ_SPLIT_PROD_HUF : LZ_SPLIT_PROD; }
+    else if (lv == 10 || lv == 30) W = fastMixed ? (huf ? LZ_WAVES_FAST_HUF : LZ_WAVES_FAST) : (huf ? LZ_WAVES_FASTLDS_HUF : LZ_WAVES_FASTLDS);
     else if (lv == 11 || lv == 31) W = LZ_WAVES_FAST18;
     else if (hcLevel)              W = LZ_WAVES_HC;
     else if (lv == 21 || lv == 41) W = pfSmall ? (huf ? LZ_PF18_W_HUF : LZ_PF18_W) : LZ_PF_W;
@@ -275,7 +277,8 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
         if (!c.pfTables) LZ_HIP(hipMalloc((void**)&c.pfTables, (size_t)c.cus * LZ_MAX_WAVES * LZ_PF_SLOT_BYTES));
         a.tables = c.pfTables; a.tableStride = LZ_PF_SLOT_BYTES;
     }
-    u32 grid = (u32)((nBlocks + W - 1) / W);
+    if (!perGroup) perGroup = W;
+    u32 grid = (u32)((nBlocks + perGroup - 1) / perGroup);
     if (grid > (u32)c.cus) grid = (u32)c.cus;
     // The scratch arena, the tables and the block counter are shared by all launches on this device: a launch
     // on another stream first waits (on the GPU) for the previous one to finish.
@@ -285,10 +288,12 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
     if (k0) LZ_HIP(hipEventRecord(k0, stream));
     const dim3 g(grid), t(64 * W);
     switch (lv) {
-    case 10: if (fastMixed) hipLaunchKernelGGL((lz_fast12_kernel<false, true>), g, t, 0, stream, a);
+    case 10: if (LZ_FAST12_SPLIT) hipLaunchKernelGGL(lz_fast12_split_kernel<false>, g, t, 0, stream, a);
+             else if (fastMixed) hipLaunchKernelGGL((lz_fast12_kernel<false, true>), g, t, 0, stream, a);
              else           hipLaunchKernelGGL((lz_fast12_kernel<false, false>), g, t, 0, stream, a);
              break;
-    case 30: if (fastMixed) hipLaunchKernelGGL((lz_fast12_kernel<true, true>), g, t, 0, stream, a);
+    case 30: if (LZ_FAST12_SPLIT) hipLaunchKernelGGL(lz_fast12_split_kernel<true>, g, t, 0, stream, a);
+             else if (fastMixed) hipLaunchKernelGGL((lz_fast12_kernel<true, true>), g, t, 0, stream, a);
              else           hipLaunchKernelGGL((lz_fast12_kernel<true, false>), g, t, 0, stream, a);
              break;
     case 11: hipLaunchKernelGGL(lz_fast18_kernel<false>, g, t, 0, stream, a); break;
@@ -630,7 +635,7 @@ int LizardGPU_residentWaves(void)
     Guard g;
     if (g.rc) return g.rc;
     int rc = ctx_init(*g.c);
-    return rc ? rc : g.c->cus * LZ_WAVES_FAST;      // level-10 residency: 13 waves per CU, every hash table in LDS
+    return rc ? rc : g.c->cus * (LZ_FAST12_SPLIT ? LZ_SPLIT_PROD : LZ_WAVES_FAST);      // level-10 residency: blocks in flight = waves with a hash table (13 per CU, all in LDS)
 }
 
 void LizardGPU_shutdown(void)

@@ -303,7 +303,7 @@ LZ_DEV void lz_encode_lz4(const u8* src, u32 S, const LzStreams& st, u8* litOut,
 //                its bytes are never fetched: most rounds issue no candidate gather at all.  Equal check
 //                bits prove nothing; those lanes still load and compare the real bytes.
 struct LzTab {
-    u16* lo; u8* hi;
+    LZ_LDS u16* lo; LZ_LDS u8* hi;
     static constexpr bool kSweeps = true;
     static constexpr bool kTagDedup = false;
     static constexpr bool kXchg = true;                              // get + put of a round in ONE LDS trip, in lane order (lz_lds_mskor_rtn2)
@@ -312,7 +312,7 @@ struct LzTab {
     {
         const u32 sl = (h & 1u) * 16u, sh = (h & 3u) * 8u;
         u32 ol, oh;
-        lz_lds_mskor_rtn2((u32*)lo + (h >> 1), 0xFFFFu << sl, (ent & 0xFFFFu) << sl, (u32*)hi + (h >> 2), 0xFFu << sh, ((ent >> 16) & 0xFFu) << sh, ol, oh);
+        lz_lds_mskor_rtn2((LZ_LDS u32*)lo + (h >> 1), 0xFFFFu << sl, (ent & 0xFFFFu) << sl, (LZ_LDS u32*)hi + (h >> 2), 0xFFu << sh, ((ent >> 16) & 0xFFu) << sh, ol, oh);
         return ((ol >> sl) & 0xFFFFu) | (((oh >> sh) & 0xFFu) << 16);
     }
     LZ_DEVM u32  entry(u32 p, u32 first4) const { return (p & 0x1FFFFu) | ((first4 * 2654435761u) >> 25 << 17); }
@@ -328,7 +328,7 @@ struct LzTab {
 // One extra slot (index 2^HASHLOG, "trash") lets lanes that must not store do so anyway, branch-free.
 // (both arrays dword-aligned, with room for the trash slot's dword: the exchanges are dword atomics)
 #define LZ_TAB_BYTES(HASHLOG) ((3u << (HASHLOG)) + 8u)
-template <int HASHLOG> LZ_DEV LzTab lz_tab_bind(void* mem) { LzTab t; t.lo = (u16*)mem; t.hi = (u8*)mem + (2u << HASHLOG) + 4u; return t; }
+template <int HASHLOG> LZ_DEV LzTab lz_tab_bind(void* mem) { LzTab t; t.lo = (LZ_LDS u16*)mem; t.hi = (LZ_LDS u8*)mem + (2u << HASHLOG) + 4u; return t; }
 // Re-stamp every slot that is dead at position Ps (age >= 65536); with `fresh`: all empty.
 template <int HASHLOG>
 LZ_DEV void lz_tab_sweep(const LzTab& t, u32 Ps, bool fresh)
@@ -349,7 +349,7 @@ template <int HASHLOG> LZ_DEV void lz_tab_fresh(const LzTab& t) { lz_tab_sweep<H
 #define LZ_WIDE_TAGLOG 11
 #endif
 struct LzTabWide {
-    u32* w;
+    LZ_GLOBAL u32* w;
     u8* tag;                                                                     // LDS, tagMask + 1 bytes
     u32 tagMask = (1u << LZ_WIDE_TAGLOG) - 1u;
     // Occupancy summary (LDS, optional): bit (h >> occShift) is set once a slot of its group has been written in this block.
@@ -383,8 +383,9 @@ struct LzTabWide {
 #define LZ_TABWIDE_BYTES(HASHLOG) ((4u << (HASHLOG)) + 64u)
 template <int HASHLOG> LZ_DEV void lz_tab_fresh(const LzTabWide& t)
 {
-    uint4 ff; ff.x = ff.y = ff.z = ff.w = 0xFFFFFFFFu;
-    for (u32 i = lz_lane() * 4u; i < (1u << HASHLOG) + 4u; i += 256u) *(uint4*)(t.w + i) = ff;   // 16 B per lane, aligned base
+    typedef u32 u32x4 __attribute__((vector_size(16)));
+    const u32x4 ff = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu };
+    for (u32 i = lz_lane() * 4u; i < (1u << HASHLOG) + 4u; i += 256u) *(LZ_GLOBAL u32x4*)(t.w + i) = ff;   // 16 B per lane, aligned base
     if (t.occ) for (u32 i = lz_lane(); i < (((1u << HASHLOG) >> t.occShift) >> 5) + 1u; i += 64u) t.occ[i] = 0u;
 }
 
@@ -604,7 +605,7 @@ LZ_DEV u32* lz_pool_acquire(const LzHufPool& pool, u32& slot)
     if (!pool.mask) return pool.base;
     for (;;) {
         lz_converge();
-        const u32 freeBits = ~lz_uniform(lz_lds_poll(pool.mask)) & ((1u << pool.count) - 1u);
+        const u32 freeBits = ~lz_lds_poll_u(pool.mask) & ((1u << pool.count) - 1u);
         if (freeBits) {
             const u32 bit = freeBits & (0u - freeBits);
             const u32 old = lz_readlane(lz_lds_atomic_or_rtn(pool.mask, lz_lane() == 0 ? bit : 0u), 0);   // branch-free claim, like lz_claim_index
@@ -712,13 +713,13 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
     // fast parser: 24-bit LDS slots up to hashLog 14, wide u32 slots in global memory above
     constexpr bool kWide = PARSER == LZ_PARSER_FAST && HASHLOG > 14;
     LzTab tab = lz_tab_bind<kWide ? 1 : HASHLOG>(tableMem);
-    LzTabWide tabw; tabw.w = (u32*)tableMem; tabw.tag = ws; tabw.tagMask = (1u << wideTagLog) - 1u;
+    LzTabWide tabw; tabw.w = (LZ_GLOBAL u32*)tableMem; tabw.tag = ws; tabw.tagMask = (1u << wideTagLog) - 1u;
     if constexpr (PARSER == LZ_PARSER_FAST && HASHLOG > 14) { tabw.occ = wideOcc; tabw.occShift = wideOcc ? (u32)HASHLOG - wideOccLog : 0u; }
     // priceFast table forms (lz_pricefast.h): u32 slots in global memory / in LDS, or the packed 18 + 6 bit LDS form
-    LzTab32G pf32g; pf32g.w = (u32*)tableMem;
+    LzTab32G pf32g; pf32g.w = (LZ_GLOBAL u32*)tableMem;
     if constexpr (PARSER == LZ_PARSER_PRICEFAST && HASHLOG > 14) { pf32g.occ = wideOcc; pf32g.occShift = wideOcc ? (u32)HASHLOG - wideOccLog : 0u; }
-    LzTab32L pf32l; pf32l.w = (u32*)tableMem; pf32l.lds = true;
-    LzTab24c pf24c; pf24c.lo = (u16*)tableMem; pf24c.hi = (u8*)tableMem + (2u << (kWide ? 1 : HASHLOG));
+    LzTab32L pf32l; pf32l.w = (LZ_LDS u32*)tableMem;
+    LzTab24c pf24c; pf24c.lo = (LZ_LDS u16*)tableMem; pf24c.hi = (LZ_LDS u8*)tableMem + (2u << (kWide ? 1 : HASHLOG));
     LzHc hc;
     if constexpr (PARSER == LZ_PARSER_HASHCHAIN) {
         const u32 row = (level >= 30u ? level - 21u : level) - 13u;                  // lizard_common.h:240-244, :264-268

@@ -11,6 +11,7 @@
 // in profiles/pmc_traffic.json speaks for the kernels only as long as these files are the ones it was measured on.
 #pragma once
 #include "lz_block.h"
+#include "lz_split.h"
 #include "lz_pack.h"
 #include "lz_unpack.h"
 
@@ -131,6 +132,48 @@ void lz_fast12_kernel(LzBatch a)
                      (HUF ? LZ_WAVES_FASTLDS_HUF : LZ_WAVES_FASTLDS)>(a);
 }
 
+// levels 10 / 30, producer / consumer form (lz_split.h): NP waves with a 12 KiB table in LDS only parse, NC waves without a table
+// run the container (encode pass, huff0) of the sub-blocks the producers hand over.  Every block size: the 17-bit relative
+// positions of LzTab have no size limit.  LZ_FAST12_SPLIT=0 builds the one-wave-per-block form above instead (tuning variants).
+#ifndef LZ_FAST12_SPLIT
+#define LZ_FAST12_SPLIT 1
+#endif
+#ifndef LZ_SPLIT_PROD
+#define LZ_SPLIT_PROD 13
+#endif
+#ifndef LZ_SPLIT_CONS
+#define LZ_SPLIT_CONS 3
+#endif
+#ifndef LZ_SPLIT_PROD_HUF
+#define LZ_SPLIT_PROD_HUF 11
+#endif
+#ifndef LZ_SPLIT_CONS_HUF
+#define LZ_SPLIT_CONS_HUF 5
+#endif
+template <bool HUF>
+__global__ __launch_bounds__(64 * (HUF ? LZ_SPLIT_PROD_HUF + LZ_SPLIT_CONS_HUF : LZ_SPLIT_PROD + LZ_SPLIT_CONS)) void lz_fast12_split_kernel(LzBatch a)
+{
+    constexpr u32 NP = HUF ? LZ_SPLIT_PROD_HUF : LZ_SPLIT_PROD, NC = HUF ? LZ_SPLIT_CONS_HUF : LZ_SPLIT_CONS;
+    static_assert(NP * LZ_SPLIT_BUFS <= LZ_SPLIT_QN, "a mailbox holds every buffer of every producer");
+    static_assert(LZ_SPLIT_ARENA_BYTES(NP, NC) <= (size_t)LZ_MAX_WAVES * LZ_SCRATCH_BYTES, "the workgroup's scratch arena");
+    static_assert(NP * 4u <= LZ_SPLIT_OPS_BYTES, "one position word per producer");
+    constexpr u32 kTabWords = LZ_TAB_BYTES(12) / 4u + 1u;
+    __shared__ u32 tables[NP][kTabWords];
+    __shared__ u64 rings[NP][LZ_SEQ_RING];
+    __shared__ u32 hufWs[HUF ? NC : 1][HUF ? LZ_HUF_WS_WORDS : 1];
+    __shared__ u32 shared[LZ_SPLIT_SHARED_WORDS(NP, NC)];
+    const u32 wave = lz_uniform(threadIdx.x >> 6);
+    const LzSplitShared sh = lz_split_shared(shared, NP, NC);
+    if (wave == 0) lz_split_shared_init(sh, NP, NC);
+    __syncthreads();
+    LzSplitArgs s;
+    s.src = a.src; s.blockSize = a.blockSize; s.nBlocks = a.nBlocks; s.lastBlockSize = a.lastBlockSize;
+    s.dst = a.dst; s.dstStride = a.dstStride; s.sizes = a.sizes; s.level = a.level; s.counter = a.counter;
+    s.arena = a.scratch + (u64)blockIdx.x * LZ_MAX_WAVES * LZ_SCRATCH_BYTES; s.nProd = NP; s.nCons = NC;
+    if (wave < NP) lz_split_producer<12>(s, sh, wave, (void*)tables[wave < NP ? wave : 0], rings[wave < NP ? wave : 0]);
+    else           lz_split_consumer<HUF>(s, sh, wave - NP, hufWs[HUF ? wave - NP : 0]);
+}
+
 // levels 11 / 31: fast parser, 2^18-slot table (u32 slots, 1 MiB per wave in global memory: L2 / Infinity Cache)
 #define LZ_WAVES_FAST18 16
 template <bool HUF>
@@ -174,22 +217,22 @@ __global__ __launch_bounds__(64 * LZ_WAVES_HC) void lz_hashchain_kernel(LzBatch 
 #define LZ_PF_TAGLOG 11
 #endif
 #ifndef LZ_PF18_W
-#define LZ_PF18_W 10
+#define LZ_PF18_W 9
 #endif
 #ifndef LZ_PF18_NLDS
-#define LZ_PF18_NLDS 4
+#define LZ_PF18_NLDS 3
 #endif
 #ifndef LZ_PF18_TAGLOG
-#define LZ_PF18_TAGLOG 11
+#define LZ_PF18_TAGLOG 10
 #endif
 #ifndef LZ_PF18_HUF_POOL
 #define LZ_PF18_HUF_POOL 3                 // Huffman workspaces shared by the waves of a level-41 workgroup (0 = one each: 3 LDS tables + 9)
 #endif
 #ifndef LZ_PF18_W_HUF
-#define LZ_PF18_W_HUF (LZ_PF18_HUF_POOL ? 10 : 12)
+#define LZ_PF18_W_HUF (LZ_PF18_HUF_POOL ? 9 : 11)
 #endif
 #ifndef LZ_PF18_NLDS_HUF
-#define LZ_PF18_NLDS_HUF (LZ_PF18_HUF_POOL ? 4 : 3)
+#define LZ_PF18_NLDS_HUF (LZ_PF18_HUF_POOL ? 3 : 2)
 #endif
 #define LZ_PF_SLOT_BYTES 65536u
 template <bool HUF, bool SMALL>
@@ -270,7 +313,7 @@ __global__ __launch_bounds__(64) void lz_selfcheck_lane_order_kernel(u32* bad, u
         __syncthreads();
         const u32 sh = (a & 1u) * 16u;
         u32 o1, o2;
-        lz_lds_mskor_rtn2(&s[a >> 1], 0xFFFFu << sh, ((lane + 1u + t) & 0xFFFFu) << sh, &s[128u + (a >> 1)], 0xFFFFu << sh, ((lane + 7u + t) & 0xFFFFu) << sh, o1, o2);
+        lz_lds_mskor_rtn2((LZ_LDS u32*)&s[a >> 1], 0xFFFFu << sh, ((lane + 1u + t) & 0xFFFFu) << sh, (LZ_LDS u32*)&s[128u + (a >> 1)], 0xFFFFu << sh, ((lane + 7u + t) & 0xFFFFu) << sh, o1, o2);
         if (((o1 >> sh) & 0xFFFFu) != (prevLane < 64u ? ((prevLane + 1u + t) & 0xFFFFu) : 0u)) nbad++;
         if (((o2 >> sh) & 0xFFFFu) != (prevLane < 64u ? ((prevLane + 7u + t) & 0xFFFFu) : 0u)) nbad++;
         __syncthreads();

@@ -50,10 +50,9 @@
 #define LZ_EMPTY24 0xFFFFFFu
 #define LZ_EMPTY18 0x3FFFFu
 struct LzTab24c {
-    u16* lo; u8* hi;
+    LZ_LDS u16* lo; LZ_LDS u8* hi;
     static constexpr u32 kEmpty = LZ_EMPTY18;
     static constexpr bool kSpecPut = true;
-    static constexpr bool kLds = true;
     LZ_DEVM static u32 pos(u32 raw) { return raw & 0x3FFFFu; }
     LZ_DEVM static u32 chk(u32 raw) { return raw >> 18; }
     LZ_DEVM static u32 chkOf(u32 first4) { return (first4 * 2654435761u) >> 26; }
@@ -65,10 +64,10 @@ struct LzTab24c {
     LZ_DEVM void sync() const { lz_lds_sync(); }
 };
 #define LZ_TAB24C_BYTES(HASHLOG) (3u << (HASHLOG))
-struct LzTab32 {
-    u32* w;
-    bool lds = false;                                            // the slots are in LDS (speculative put + read-back finds same-slot lanes)
+struct LzTab32G {                                                // slots in a global-memory slot of the wave
+    LZ_GLOBAL u32* w;
     static constexpr u32 kEmpty = LZ_EMPTY24;
+    static constexpr bool kSpecPut = false;
     LZ_DEVM static u32 pos(u32 raw) { return raw & 0xFFFFFFu; }
     LZ_DEVM static u32 chk(u32 raw) { return raw >> 24; }
     LZ_DEVM static u32 chkOf(u32 first4) { return (first4 * 2654435761u) >> 24; }
@@ -76,6 +75,8 @@ struct LzTab32 {
     // Occupancy summary (LDS, optional; levels 22/42 with their 2^18 slots): as LzTabWide::occ in lz_block.h
     u32* occ = nullptr;
     u32 occShift = 0;
+    LZ_DEVM void specPut(u32, u32) const {}
+    LZ_DEVM bool specLost(u32, u32) const { return false; }
     LZ_DEVM u32  get(u32 h) const
     {
         if (!occ) return w[h];
@@ -89,32 +90,33 @@ struct LzTab32 {
         w[h] = v;
         if (occ) { const u32 b = h >> occShift; lz_lds_atomic_or(&occ[b >> 5], 1u << (b & 31u)); }
     }
-};
-// the two residences of LzTab32 as types (the parser is compiled once per form)
-struct LzTab32G : LzTab32 {
-    static constexpr bool kSpecPut = false;
-    static constexpr bool kLds = false;
-    LZ_DEVM void specPut(u32, u32) const {}
-    LZ_DEVM bool specLost(u32, u32) const { return false; }
     LZ_DEVM void sync() const { lz_wave_sync(); }
 };
-struct LzTab32L : LzTab32 {
+struct LzTab32L {                                                // the same slots in LDS
+    LZ_LDS u32* w;
+    static constexpr u32 kEmpty = LZ_EMPTY24;
     static constexpr bool kSpecPut = true;
-    static constexpr bool kLds = true;
+    LZ_DEVM static u32 pos(u32 raw) { return raw & 0xFFFFFFu; }
+    LZ_DEVM static u32 chk(u32 raw) { return raw >> 24; }
+    LZ_DEVM static u32 chkOf(u32 first4) { return (first4 * 2654435761u) >> 24; }
+    LZ_DEVM static u32 make(u32 p, u32 c) { return p | (c << 24); }
     // speculative put of the low half only: the position's low 16 bits tell the lanes of a round apart (they differ by < 64)
-    LZ_DEVM void specPut(u32 h, u32 p) const { ((u16*)w)[2u * h] = (u16)p; }
-    LZ_DEVM bool specLost(u32 h, u32 p) const { return ((u16*)w)[2u * h] != (u16)p; }
+    LZ_DEVM void specPut(u32 h, u32 p) const { ((LZ_LDS u16*)w)[2u * h] = (u16)p; }
+    LZ_DEVM bool specLost(u32 h, u32 p) const { return ((LZ_LDS u16*)w)[2u * h] != (u16)p; }
+    LZ_DEVM u32  get(u32 h) const { return w[h]; }
+    LZ_DEVM void set(u32 h, u32 v) const { w[h] = v; }
     LZ_DEVM void sync() const { lz_lds_sync(); }
 };
-template <int HASHLOG> LZ_DEV void lz_pf_tab_fresh(const LzTab32& t)
+template <int HASHLOG> LZ_DEV void lz_pf_tab_fresh(const LzTab32L& t) { for (u32 i = lz_lane(); i < (1u << HASHLOG); i += 64u) t.w[i] = LZ_EMPTY24; }
+template <int HASHLOG> LZ_DEV void lz_pf_tab_fresh(const LzTab32G& t)
 {
     for (u32 i = lz_lane(); i < (1u << HASHLOG); i += 64u) t.w[i] = LZ_EMPTY24;
     if (t.occ) for (u32 i = lz_lane(); i < (((1u << HASHLOG) >> t.occShift) >> 5); i += 64u) t.occ[i] = 0u;
 }
 template <int HASHLOG> LZ_DEV void lz_pf_tab_fresh(const LzTab24c& t)
 {
-    for (u32 i = lz_lane(); i < (1u << HASHLOG) / 2u; i += 64u) ((u32*)t.lo)[i] = 0xFFFFFFFFu;
-    for (u32 i = lz_lane(); i < (1u << HASHLOG) / 4u; i += 64u) ((u32*)t.hi)[i] = 0x03030303u;     // position bits 16-17 set, check bits 0
+    for (u32 i = lz_lane(); i < (1u << HASHLOG) / 2u; i += 64u) ((LZ_LDS u32*)t.lo)[i] = 0xFFFFFFFFu;
+    for (u32 i = lz_lane(); i < (1u << HASHLOG) / 4u; i += 64u) ((LZ_LDS u32*)t.hi)[i] = 0x03030303u;     // position bits 16-17 set, check bits 0
 }
 
 // ---- sequence list (LIZv1): L < 2^18, ml < 2^18, off < 2^24 (0 = repeat the last offset) ----

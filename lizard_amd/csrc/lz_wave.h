@@ -20,6 +20,12 @@ typedef uint64_t u64;
 #define LZ_DEVM __device__ __forceinline__       /* member functions */
 #define LZ_DEV_NOINLINE __device__ __noinline__
 #define LZ_WAVE 64
+// A pointer into LDS, typed as such: accesses through it are DS instructions with a 32-bit address.  A table pointer that is
+// picked at run time ("this wave's table is in LDS, that one's in global memory") is a generic pointer to the compiler, and
+// accesses through a generic pointer are FLAT instructions — 64-bit addresses in VGPR pairs, and counted in vmcnt AND lgkmcnt, so
+// that every wait for one of them also waits for all global loads in flight.  The table forms that live in LDS cast once.
+#define LZ_LDS __attribute__((address_space(3)))
+#define LZ_GLOBAL __attribute__((address_space(1)))            /* likewise for a table in the wave's global-memory slot: global_*, not flat_* */
 
 // lane index inside the wavefront (workgroups are launched with blockDim.x a multiple of 64)
 LZ_DEV u32 lz_lane() { return threadIdx.x & 63u; }
@@ -96,6 +102,25 @@ LZ_DEV u32 lz_lds_atomic_or_rtn(u32* p, u32 v) { return atomicOr(p, v); }
 LZ_DEV void lz_lds_atomic_and(u32* p, u32 v) { atomicAnd(p, v); }
 LZ_DEV u32 lz_lds_poll(const u32* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
 LZ_DEV void lz_sleep() { __builtin_amdgcn_s_sleep(8); }
+// the same word as every lane of the wave sees it in ONE read (wave-uniform)
+LZ_DEV u32 lz_lds_poll_u(const u32* p) { return lz_uniform(lz_lds_poll(p)); }
+// Words shared between the WAVES of a workgroup (lz_split.h: mailboxes, free masks, counters).
+//   lz_lds_claim       take the next ticket of an LDS counter: one atomic per wave, result wave-uniform (branch-free like lz_claim_index)
+//   lz_lds_store       store of a word other waves poll (lz_lds_poll)
+//   lz_publish_release / lz_publish_acquire   around such a word when it announces GLOBAL-memory data written by this wave / to be read
+//                      by this wave: all earlier stores of every lane have completed (agent scope) before the word is stored; the
+//                      vector L1 is invalidated after the word was seen, so reused buffers are re-read from L2
+//   lz_ld_shared_u32 / lz_st_shared_u32        a global-memory word handed between waves (never served from the scalar cache)
+LZ_DEV u32 lz_lds_claim(u32* counter)
+{
+    const u32 old = atomicAdd(counter, lz_lane() == 0 ? 1u : 0u);
+    return lz_readlane(old, 0);
+}
+LZ_DEV void lz_lds_store(u32* p, u32 v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
+LZ_DEV void lz_publish_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_wave_barrier(); }
+LZ_DEV void lz_publish_acquire() { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+LZ_DEV u32 lz_ld_shared_u32(const u32* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+LZ_DEV void lz_st_shared_u32(u32* p, u32 v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
 // Masked bit-field store into an LDS dword, atomic per lane: *p = (*p & ~mask) | val  (ds_mskor_b32).  Lanes of one
 // instruction may target different fields of the same dword.  val must lie inside mask.
 LZ_DEV void lz_lds_mskor(u32* p, u32 mask, u32 val)
@@ -148,7 +173,7 @@ LZ_DEV void lz_st64(u8* p, u64 v) { reinterpret_cast<lz_u64u*>(p)->v = v; }
 // hit the same dword are served in ascending lane order on gfx950 (tests/lds_atomic_order.hip: 0 violations in
 // 2.5 M colliding wave-instructions; pinned by tests/test_gpu_parity.py::test_lds_atomics_are_served_in_lane_order): a later lane
 // of a round sees an earlier lane's update — the in-order view of a serial hash-table walk, for free.
-LZ_DEV void lz_lds_mskor_rtn2(u32* pa, u32 ma, u32 va, u32* pb, u32 mb, u32 vb, u32& oa, u32& ob)
+LZ_DEV void lz_lds_mskor_rtn2(LZ_LDS u32* pa, u32 ma, u32 va, LZ_LDS u32* pb, u32 mb, u32 vb, u32& oa, u32& ob)
 {
     asm volatile("ds_mskor_rtn_b32 %0, %2, %3, %4\n\tds_mskor_rtn_b32 %1, %5, %6, %7\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(oa), "=&v"(ob)

@@ -14,7 +14,7 @@ def build(force=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
     cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-fno-omit-frame-pointer", "-Wall", "-Wextra",
-           "-Wno-unused-function", "-I", HERE, "-o", OUT] + SRCS
+           "-Wno-unused-function", "-Wno-unknown-pragmas", "-pthread", "-I", HERE, "-o", OUT] + SRCS
     subprocess.check_call(cmd)
     return OUT
 

@@ -3,6 +3,9 @@
 #include "lz_wave.h"            // tests/emul/lz_wave.h (emulator) — must come first, see the shared guard
 #include "../../lizard_amd/csrc/lz_block.h"
 #include "../../lizard_amd/csrc/lz_unpack.h"
+#include "../../lizard_amd/csrc/lz_split.h"
+#include <thread>
+#include <vector>
 
 namespace {
 struct Args { const u8* src; u32 n; u8* dst; u32 level; u32* table; u8* tag; u8* scratch; u64* ring; u32 result; u32 tabKind; u32* hcRegion; u32 maxBlock; u32 poolMask; u32* wideOcc; };
@@ -43,7 +46,7 @@ extern "C" int emul_compress_block(const void* src, int n, void* dst, int level,
     if (hcLevel && (size_t)n > kHcMaxBlock) return -1;
     a.src = (const u8*)src; a.n = (u32)n; a.dst = (u8*)dst; a.level = (u32)level; a.result = 0;
     // odd seeds run the u32-slot (global-memory) table layout of the mixed-residency kernels; seeds = 2 mod 4 the packed
-    // 18-bit LDS table of the priceFast kernel for blocks up to 256 KiB
+    // 18 + 6 bit LDS table of the priceFast kernel for blocks up to 256 KiB; the others the u32-slot LDS form
     a.tabKind = ((base == 21 || base == 22 || base == 10) && (seed & 1u)) ? LZ_TABKIND_GLOBAL
               : (base == 21 && n <= (1 << 18) && (seed & 3u) == 2u) ? LZ_TABKIND_LDS18 : LZ_TABKIND_LDS;
     a.table = (u32*)aligned_alloc(64, (sizeof(u32) << hashLog) + 64);
@@ -175,4 +178,53 @@ extern "C" int emul_decompress_block(const void* src, int n, void* dst, int cap,
     lzemu::run_wave(entry_dec, &a, seed);
     free(a.stage); free(a.ws);
     return a.result == LZD_ERR ? -1 : (int)a.result;
+}
+
+
+// Levels 10 / 30 in the producer / consumer form (lizard_amd/csrc/lz_split.h): nProd + nCons emulated waves, each on an OS thread
+// of its own, share one "LDS" (mailboxes, free masks, counters) and one scratch arena, exactly as the waves of one workgroup of
+// lz_fast12_split_kernel do.  Block i is src + i*blockSize (the last one lastBlockSize bytes) -> dst + i*dstStride, sizes[i].
+namespace {
+struct SplitWave { LzSplitArgs a; LzSplitShared sh; u32 wave; void* table; u64* ring; u32* hufWs; bool huf; };
+void entry_split_init(void* p) { SplitWave* w = (SplitWave*)p; lz_split_shared_init(w->sh, w->a.nProd, w->a.nCons); }
+void entry_split(void* p)
+{
+    SplitWave* w = (SplitWave*)p;
+    if (w->wave < w->a.nProd) lz_split_producer<12>(w->a, w->sh, w->wave, w->table, w->ring);
+    else if (w->huf)          lz_split_consumer<true>(w->a, w->sh, w->wave - w->a.nProd, w->hufWs);
+    else                      lz_split_consumer<false>(w->a, w->sh, w->wave - w->a.nProd, w->hufWs);
+}
+}  // namespace
+
+extern "C" int emul_compress_split(const void* src, int nBlocks, int blockSize, int lastBlockSize, void* dst, int dstStride,
+                                   unsigned* sizes, int level, int nProd, int nCons, unsigned seed)
+{
+    if ((level != 10 && level != 30) || nProd < 1 || nCons < 1 || (u32)nProd * LZ_SPLIT_BUFS > LZ_SPLIT_QN) return -1;
+    LzSplitArgs a;
+    a.src = (const u8*)src; a.blockSize = (u64)blockSize; a.nBlocks = (u32)nBlocks; a.lastBlockSize = (u32)lastBlockSize;
+    a.dst = (u8*)dst; a.dstStride = (u64)dstStride; a.sizes = sizes; a.level = (u32)level;
+    u32 counter = 0; a.counter = &counter;
+    const size_t arenaBytes = LZ_SPLIT_ARENA_BYTES((size_t)nProd, (size_t)nCons);
+    a.arena = (u8*)malloc(arenaBytes); memset(a.arena, 0xC7, arenaBytes);
+    a.nProd = (u32)nProd; a.nCons = (u32)nCons;
+    std::vector<u32> shared(LZ_SPLIT_SHARED_WORDS((u32)nProd, (u32)nCons), 0xA5A5A5A5u);
+    const LzSplitShared sh = lz_split_shared(shared.data(), (u32)nProd, (u32)nCons);
+    const size_t tabBytes = LZ_TAB_BYTES(12) + 64;
+    std::vector<u8> tables((size_t)nProd * tabBytes, 0x5A);
+    std::vector<u64> rings((size_t)nProd * LZ_SEQ_RING, 0xEEEEEEEEEEEEEEEEull);
+    std::vector<u32> ws((size_t)nCons * LZ_HUF_WS_WORDS, 0x77777777u);
+    std::vector<SplitWave> waves((size_t)(nProd + nCons));
+    for (int w = 0; w < nProd + nCons; w++) {
+        SplitWave& x = waves[(size_t)w];
+        x.a = a; x.sh = sh; x.wave = (u32)w; x.huf = level >= 30;
+        x.table = w < nProd ? (void*)&tables[(size_t)w * tabBytes] : nullptr;
+        x.ring = w < nProd ? &rings[(size_t)w * LZ_SEQ_RING] : nullptr;
+        x.hufWs = w >= nProd ? &ws[(size_t)(w - nProd) * LZ_HUF_WS_WORDS] : nullptr;
+    }
+    lzemu::run_wave(entry_split_init, &waves[0], seed);
+    std::vector<std::thread> th;
+    for (int w = 0; w < nProd + nCons; w++) th.emplace_back([&waves, w, seed] { lzemu::run_wave(entry_split, &waves[(size_t)w], seed * 31u + (unsigned)w + 1u); });
+    for (auto& t : th) t.join();
+    free(a.arena);
+    return 0;
 }

@@ -16,6 +16,7 @@
 // cross-lane op) aborts.
 #ifndef LZ_WAVE_H_
 #define LZ_WAVE_H_   /* shared guard: the first lz_wave.h seen (gfx950 or test emulator) wins */
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -31,6 +32,8 @@ struct uint4 { uint32_t x, y, z, w; };
 #define LZ_DEVM inline
 #define LZ_DEV_NOINLINE static __attribute__((noinline))
 #define LZ_WAVE 64
+#define LZ_LDS                 /* address-space qualifier of LDS pointers on the device; nothing here */
+#define LZ_GLOBAL
 
 namespace lzemu {
 
@@ -116,12 +119,28 @@ LZ_DEV u32 lz_ctz64(u64 m) { return (u32)__builtin_ctzll(m); }
 LZ_DEV u32 lz_clz64(u64 m) { return (u32)__builtin_clzll(m); }
 LZ_DEV u32 lz_popc64(u64 m) { return (u32)__builtin_popcountll(m); }
 
-LZ_DEV void lz_lds_atomic_add(u32* p, u32 v) { *p += v; }
-LZ_DEV void lz_lds_atomic_or(u32* p, u32 v) { *p |= v; }
-LZ_DEV u32 lz_lds_atomic_or_rtn(u32* p, u32 v) { const u32 o = *p; *p |= v; return o; }
-LZ_DEV void lz_lds_atomic_and(u32* p, u32 v) { *p &= v; }
-LZ_DEV u32 lz_lds_poll(const u32* p) { return *p; }
-LZ_DEV void lz_sleep() {}
+// Words shared between waves: several emulated waves run on OS threads of their own (emul_compress_split), so these are real atomics
+// and a sleeping wave gives its core away.
+LZ_DEV void lz_lds_atomic_add(u32* p, u32 v) { __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+LZ_DEV void lz_lds_atomic_or(u32* p, u32 v) { __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+LZ_DEV u32 lz_lds_atomic_or_rtn(u32* p, u32 v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+LZ_DEV void lz_lds_atomic_and(u32* p, u32 v) { __atomic_fetch_and(p, v, __ATOMIC_SEQ_CST); }
+LZ_DEV u32 lz_lds_poll(const u32* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+LZ_DEV void lz_sleep() { sched_yield(); }
+// one read per wave (another wave's thread may change the word between two lanes' turns)
+LZ_DEV u32 lz_lds_poll_u(const u32* p) { u32 v = 0; if (lz_lane() == 0) v = lz_lds_poll(p); return lz_readlane(v, 0); }
+LZ_DEV u32 lz_lds_claim(u32* counter)
+{
+    u32 old = 0;
+    if (lz_lane() == 0) old = __atomic_fetch_add(counter, 1u, __ATOMIC_SEQ_CST);
+    return lz_readlane(old, 0);
+}
+LZ_DEV u32 lz_claim_index(u32* counter) { return lz_lds_claim(counter); }
+LZ_DEV void lz_lds_store(u32* p, u32 v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
+LZ_DEV void lz_publish_release() { lzemu::park(lzemu::OP_SYNC); __atomic_thread_fence(__ATOMIC_SEQ_CST); }   // every lane's stores are done
+LZ_DEV void lz_publish_acquire() { __atomic_thread_fence(__ATOMIC_SEQ_CST); lzemu::park(lzemu::OP_SYNC); }
+LZ_DEV u32 lz_ld_shared_u32(const u32* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+LZ_DEV void lz_st_shared_u32(u32* p, u32 v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
 // returning masked exchanges: the hardware serves the lanes of one instruction in ascending lane order — the scheduler does too
 LZ_DEV void lz_lds_mskor_rtn2(u32* pa, u32 ma, u32 va, u32* pb, u32 mb, u32 vb, u32& oa, u32& ob)
 {

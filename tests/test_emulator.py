@@ -150,3 +150,34 @@ def test_emulated_wave_helpers():
     emu.emul_check_helpers.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint]
     for seed in (1, 2, 3):
         assert emu.emul_check_helpers(bytes(buf), n, arr, len(triples) // 3, seed) == 0
+
+
+def emul_split(data, bs, level, nprod, ncons, seed=1):
+    """Levels 10 / 30 in the producer / consumer form (lizard_amd/csrc/lz_split.h) on nprod + ncons emulated waves, each on an OS
+    thread of its own, sharing mailboxes and free masks like the waves of one workgroup; returns the compressed blocks."""
+    emu = util.emulator()
+    emu.emul_compress_split.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint]
+    nb = (len(data) + bs - 1) // bs
+    last = len(data) - (nb - 1) * bs
+    stride = util.oracle().lzo_compress_bound(bs) + 64
+    dst = ctypes.create_string_buffer(nb * stride)
+    sizes = (ctypes.c_uint * nb)()
+    src = ctypes.create_string_buffer(bytes(data), len(data))
+    assert emu.emul_compress_split(src, nb, bs, last, dst, stride, sizes, level, nprod, ncons, seed) == 0
+    return [dst.raw[i * stride:i * stride + sizes[i]] for i in range(nb)]
+
+
+@pytest.mark.parametrize("level", [10, 30])
+def test_emulated_split_producers_and_consumers(level):
+    """Parse and container on different waves: every block must come out as the one-wave form (= the oracle) writes it —
+    many blocks per producer, sub-block chains (blocks of 1 to 9 sub-blocks), ragged last blocks, tiny blocks, more consumers
+    than producers and the reverse, the kernel's own wave counts (13 + 3, 11 + 5)."""
+    data = util.datagen(1500000, 0.5, 0.0, 3) + bytes(70000) + util.datagen(300000, 0.2, 0.0, 9) + b"abcd" * 5000 + util.datagen(7, 0.5, 0.0, 1)
+    shapes = [(65536, 3, 1), (262144, 2, 2), (300000, 4, 2), (40000, 5, 3), (1 << 20, 1, 1), (19, 2, 1), (131072, 1, 3)]
+    shapes.append((30000, 13, 3) if level == 10 else (30000, 11, 5))
+    for bs, nprod, ncons in shapes:
+        part = data if bs > 100 else data[:1000]
+        outs = emul_split(part, bs, level, nprod, ncons, seed=bs + nprod)
+        for i, o in enumerate(outs):
+            assert o == util.oracle_compress(part[i * bs:(i + 1) * bs], level), (level, bs, nprod, ncons, i)
