@@ -63,7 +63,7 @@ def kernel_name(level, bs):
     if level >= 34 and level <= 38:
         base = level - 21
     if base == 10:
-        return "lz_fast12_kernel<%s, %s>" % (huf, "true" if bs <= (4 << 20) else "false")
+        return "lz_fast12_split_kernel<%s>" % huf
     if base == 11:
         return "lz_fast18_kernel<%s>" % huf
     if base == 21:

@@ -214,13 +214,14 @@ int clamp_level(int level)                                       // reference li
     return level;
 }
 
-// Largest block the GPU path takes at a level (0 = level not on the GPU path).
+// Largest block the GPU path takes at a level (0 = level not on the GPU path).  The table forms of the fast and priceFast
+// parsers keep positions modulo a power of two and sweep (lz_block.h, lz_pricefast.h): any size the reference takes
+// (lib/lizard_compress.h:121).  hashChain: 22-bit positions in its bin entries, blocks up to 4 MiB.
 size_t level_max_block(int lv)
 {
     const bool hcLevel = (lv >= 13 && lv <= 17) || (lv >= 34 && lv <= 38);
-    if (lv == 10 || lv == 30) return (size_t)LIZARD_MAX_INPUT_SIZE;
-    if (lv == 11 || lv == 31 || hcLevel) return (size_t)4 << 20;           // 22-bit positions
-    if (lv == 21 || lv == 41 || lv == 22 || lv == 42) return ((size_t)1 << 24) - 2u;   // 24-bit positions (lz_pricefast.h)
+    if (lv == 10 || lv == 30 || lv == 11 || lv == 31 || lv == 21 || lv == 41 || lv == 22 || lv == 42) return (size_t)LIZARD_MAX_INPUT_SIZE;
+    if (hcLevel) return (size_t)4 << 20;
     return 0;
 }
 

@@ -53,7 +53,7 @@ struct LzStreams {
                                                         // coalesced bursts — gfx950 counts stores in vmcnt, so a global
                                                         // store per sequence would sit in front of every later load wait
     u32 lastLits;                                       // uniform: trailing literals of the sub-block (fast.h:187-190)
-    u32 sweepAt;                                        // uniform: position at which the 17-bit table is swept next
+    u32 sweepAt;                                        // uniform: position at which the table is swept next (tables with positions modulo a power of two)
 #ifdef LZ_PROFILE
     u64 prof_last; u64 prof[16];                         // shader-clock deltas per phase (profile builds only)
 #endif
@@ -305,6 +305,7 @@ LZ_DEV void lz_encode_lz4(const u8* src, u32 S, const LzStreams& st, u8* litOut,
 struct LzTab {
     LZ_LDS u16* lo; LZ_LDS u8* hi;
     static constexpr bool kSweeps = true;
+    static constexpr u32  kSweepEvery = 32768u;                      // positions between two sweeps
     static constexpr bool kTagDedup = false;
     static constexpr bool kXchg = true;                              // get + put of a round in ONE LDS trip, in lane order (lz_lds_mskor_rtn2)
     // put `ent` into slot h and return the slot's previous value (as seen after the puts of all lower lanes of this instruction)
@@ -317,6 +318,7 @@ struct LzTab {
     }
     LZ_DEVM u32  entry(u32 p, u32 first4) const { return (p & 0x1FFFFu) | ((first4 * 2654435761u) >> 25 << 17); }
     LZ_DEVM u32  get(u32 h) const { return (u32)lo[h] | ((u32)hi[h] << 16); }
+    LZ_DEVM u32  get(u32 h, u32) const { return get(h); }
     LZ_DEVM void set(u32 h, u32 ent) const { lo[h] = (u16)ent; hi[h] = (u8)(ent >> 16); }
     // age of a slot seen from position p (0..131071); usable iff 8 <= age <= 65535 (+ the lowLimit rule)
     LZ_DEVM u32  age(u32 p, u32 ent) const { return (p - ent) & 0x1FFFFu; }
@@ -340,11 +342,13 @@ LZ_DEV void lz_tab_sweep(const LzTab& t, u32 Ps, bool fresh)
 template <int HASHLOG> LZ_DEV void lz_tab_fresh(const LzTab& t) { lz_tab_sweep<HASHLOG>(t, 0, true); }
 
 // Wide variant for tables that do not fit LDS (hashLog 18: levels 11/31; 1 MiB per wave in global memory —
-// 4 GiB over the resident waves, so every access is a random HBM sector): u32 slots, bits 0..21 = position
-// (blocks up to 4 MiB), bits 22..31 = check hash, 0xFFFFFFFF = empty.  Full positions need no sweep;
-// cross-lane ordering needs the full wave sync.  Table accesses are what a round costs here, so same-slot
-// lanes of a round are found through a small LDS tag array (as in lz_pricefast.h) instead of put + read-back,
-// and nothing is stored speculatively: one gather and one scatter per round.
+// 4 GiB over the resident waves, so every access is a random HBM sector): u32 slots, bits 0..21 = position mod 2^22,
+// bits 22..31 = check hash.  Like LzTab's 17 bits, 22 bits are exact for any block size because the reference only
+// accepts distances <= 65535 (fast.h:90): a sweep every 2^20 positions re-stamps every slot that is dead by then (age
+// >= 65536) as "exactly 2^21 old", which is also what a fresh table holds — no slot ever gets older than 2^22 - 1.
+// (A 256 KiB or 4 MiB block never sweeps.)  Cross-lane ordering needs the full wave sync.  Table accesses are what a round
+// costs here, so same-slot lanes of a round are found through a small LDS tag array (as in lz_pricefast.h) instead of
+// put + read-back, and nothing is stored speculatively: one gather and one scatter per round.
 #ifndef LZ_WIDE_TAGLOG
 #define LZ_WIDE_TAGLOG 11
 #endif
@@ -353,41 +357,54 @@ struct LzTabWide {
     u8* tag;                                                                     // LDS, tagMask + 1 bytes
     u32 tagMask = (1u << LZ_WIDE_TAGLOG) - 1u;
     // Occupancy summary (LDS, optional): bit (h >> occShift) is set once a slot of its group has been written in this block.
-    // A probe whose bit is clear finds an empty slot without touching the table: with 2^18 slots and at most 2^17 insertions
+    // A probe whose bit is clear finds a dead slot without touching the table: with 2^18 slots and at most 2^17 insertions
     // per 256 KiB block most probes do — and a probe is a random 128-byte line.
     u32* occ = nullptr;
     u32 occShift = 0;
-    static constexpr bool kSweeps = false;
+    static constexpr bool kSweeps = true;
+    static constexpr u32  kSweepEvery = 1u << 20;
     static constexpr bool kTagDedup = true;
     static constexpr bool kXchg = false;
     LZ_DEVM u32 xchg(u32, u32) const { return 0; }
-    LZ_DEVM u32  entry(u32 p, u32 first4) const { return p | ((first4 * 2654435761u) >> 22 << 22); }
-    LZ_DEVM u32  get(u32 h) const
+    LZ_DEVM static u32 dead(u32 p) { return (p - (1u << 21)) & 0x3FFFFFu; }      // a slot value that is 2^21 old at position p
+    LZ_DEVM u32  entry(u32 p, u32 first4) const { return (p & 0x3FFFFFu) | ((first4 * 2654435761u) >> 22 << 22); }
+    LZ_DEVM u32  get(u32 h, u32 p) const
     {
         if (!occ) return w[h];
         const u32 b = h >> occShift;
         const bool oc = (occ[b >> 5] >> (b & 31u)) & 1u;
         const u32 v = w[oc ? h : 0u];                                            // unconditional load (slot 0 for the lanes that need none)
-        return oc ? v : 0xFFFFFFFFu;
+        return oc ? v : dead(p);
     }
     LZ_DEVM void set(u32 h, u32 ent) const
     {
         w[h] = ent;
         if (occ) { const u32 b = h >> occShift; lz_lds_atomic_or(&occ[b >> 5], 1u << (b & 31u)); }   // (the trash slot sets the spare bit)
     }
-    LZ_DEVM u32  age(u32 p, u32 ent) const { return p - (ent & 0x3FFFFFu); }     // empty / not-before-p slots wrap to > 65535
+    LZ_DEVM u32  age(u32 p, u32 ent) const { return (p - ent) & 0x3FFFFFu; }     // dead slots: >= 65536
     LZ_DEVM bool sameCheck(u32 a, u32 b) const { return ((a ^ b) >> 22) == 0; }
     LZ_DEVM bool lostPut(u32 h, u32 mine) const { return w[h] != mine; }
     LZ_DEVM void sync() const { lz_wave_sync(); }
 };
 #define LZ_TABWIDE_BYTES(HASHLOG) ((4u << (HASHLOG)) + 64u)
-template <int HASHLOG> LZ_DEV void lz_tab_fresh(const LzTabWide& t)
+// Re-stamp every slot that is dead at position Ps (with `fresh`: every slot), 16 bytes per lane; the occupancy summary stays
+// as it is (fresh: cleared) — a re-stamped slot is as good as a never-written one.
+template <int HASHLOG>
+LZ_DEV void lz_tab_sweep(const LzTabWide& t, u32 Ps, bool fresh)
 {
     typedef u32 u32x4 __attribute__((vector_size(16)));
-    const u32x4 ff = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu };
-    for (u32 i = lz_lane() * 4u; i < (1u << HASHLOG) + 4u; i += 256u) *(LZ_GLOBAL u32x4*)(t.w + i) = ff;   // 16 B per lane, aligned base
-    if (t.occ) for (u32 i = lz_lane(); i < (((1u << HASHLOG) >> t.occShift) >> 5) + 1u; i += 64u) t.occ[i] = 0u;
+    const u32 d = LzTabWide::dead(Ps);
+    for (u32 i = lz_lane() * 4u; i < (1u << HASHLOG) + 4u; i += 256u) {         // (aligned base; the 4 words behind the table are the trash slot's)
+        u32x4 v = { d, d, d, d };
+        if (!fresh) {
+            const u32x4 o = *(LZ_GLOBAL u32x4*)(t.w + i);
+            for (int k = 0; k < 4; k++) v[k] = t.age(Ps, o[k]) >= 65536u ? d : o[k];
+        }
+        *(LZ_GLOBAL u32x4*)(t.w + i) = v;
+    }
+    if (fresh && t.occ) for (u32 i = lz_lane(); i < (((1u << HASHLOG) >> t.occShift) >> 5) + 1u; i += 64u) t.occ[i] = 0u;
 }
+template <int HASHLOG> LZ_DEV void lz_tab_fresh(const LzTabWide& t) { lz_tab_sweep<HASHLOG>(t, 0, true); }
 
 // Position handled by `slot` of the current run.  A run that follows a match ("special") spends its first
 // two slots on the reference's post-match steps: slot 0 = put(ip-2) only (fast.h:146), slot 1 = the
@@ -422,7 +439,7 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
     // fast.h:57-58 in block-relative positions: lowLimit is fixed at sub-block entry
     const u32 lowPos = S > LZ_MAX_DIST_LZ4 ? S - LZ_MAX_DIST_LZ4 : 0u;
 
-    if constexpr (TAB::kSweeps) if (S >= st.sweepAt) { lz_tab_sweep<HASHLOG>(table, S, false); st.sweepAt = S + 32768u; table.sync(); }
+    if constexpr (TAB::kSweeps) if (S >= st.sweepAt) { lz_tab_sweep<HASHLOG>(table, S, false); st.sweepAt = S + TAB::kSweepEvery; table.sync(); }
     if (lane == 0) { const u64 b0 = lz_ld64(src + S); table.set(lz_hash5<HASHLOG>(b0), table.entry(S, (u32)b0)); }   // fast.h:66
     table.sync();
 
@@ -451,7 +468,7 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
             }
             if constexpr (TAB::kSweeps) {   // keep every live slot younger than 2^17 positions (see LzTab)
                 const u32 p0 = lz_readlane(p, 0);
-                if (p0 >= st.sweepAt) { lz_tab_sweep<HASHLOG>(table, p0, false); st.sweepAt = p0 + 32768u; table.sync(); }
+                if (p0 >= st.sweepAt) { lz_tab_sweep<HASHLOG>(table, p0, false); st.sweepAt = p0 + TAB::kSweepEvery; table.sync(); }
             }
             // (slots past mflimit hold stale bytes and a meaningless hash; `valid` keeps them out of every decision
             //  and their stores go to the trash slot — the round itself is branch-free up to the candidate batch)
@@ -467,7 +484,7 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
                 // Visits after the winner never happened: they are taken back once the winner is known (below).
                 e = table.xchg(valid ? h : (1u << HASHLOG), mine);
             } else {
-            e = table.get(h);                                            // value before this round
+            e = table.get(h, p);                                         // value before this round
             bool lost;
             if constexpr (TAB::kTagDedup) {                              // same-slot lanes found through LDS; nothing stored yet
                 const u32 ti = h & table.tagMask;
@@ -727,14 +744,14 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
         lz_hc_build<AUX>(src, n, hc, *hcPool, st);
         lz_hc_hits(src, n, hc);
     }
-    else if constexpr (kWide) lz_tab_fresh<HASHLOG>(tabw);
+    else if constexpr (kWide) { lz_tab_fresh<HASHLOG>(tabw); st.sweepAt = LzTabWide::kSweepEvery; }
     else if constexpr (PARSER == LZ_PARSER_FAST) {
-        if (tabKind == LZ_TABKIND_GLOBAL) lz_tab_fresh<HASHLOG>(tabw);
-        else { lz_tab_fresh<HASHLOG>(tab); st.sweepAt = 32768u; }
+        if (tabKind == LZ_TABKIND_GLOBAL) { lz_tab_fresh<HASHLOG>(tabw); st.sweepAt = LzTabWide::kSweepEvery; }
+        else { lz_tab_fresh<HASHLOG>(tab); st.sweepAt = LzTab::kSweepEvery; }
     }
-    else if (tabKind == LZ_TABKIND_GLOBAL) lz_pf_tab_fresh<HASHLOG>(pf32g);
+    else if (tabKind == LZ_TABKIND_GLOBAL) { lz_pf_tab_fresh<HASHLOG>(pf32g); st.sweepAt = LZ_PF_SWEEP_EVERY; }
     else if (tabKind == LZ_TABKIND_LDS18)  lz_pf_tab_fresh<HASHLOG>(pf24c);
-    else                                   lz_pf_tab_fresh<HASHLOG>(pf32l);
+    else                                   { lz_pf_tab_fresh<HASHLOG>(pf32l); st.sweepAt = LZ_PF_SWEEP_EVERY; }
     lz_wave_sync();
     LZ_PROF(st, 6);                                           // table init
     if (lane == 0) dst[0] = (u8)level;                        // lizard_compress.c:488

@@ -145,10 +145,10 @@ void lz_fast12_kernel(LzBatch a)
 #define LZ_SPLIT_CONS 3
 #endif
 #ifndef LZ_SPLIT_PROD_HUF
-#define LZ_SPLIT_PROD_HUF 11
+#define LZ_SPLIT_PROD_HUF 10
 #endif
 #ifndef LZ_SPLIT_CONS_HUF
-#define LZ_SPLIT_CONS_HUF 5
+#define LZ_SPLIT_CONS_HUF 6
 #endif
 template <bool HUF>
 __global__ __launch_bounds__(64 * (HUF ? LZ_SPLIT_PROD_HUF + LZ_SPLIT_CONS_HUF : LZ_SPLIT_PROD + LZ_SPLIT_CONS)) void lz_fast12_split_kernel(LzBatch a)
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64 * LZ_WAVES_HC) void lz_hashchain_kernel(LzBatch 
 #define LZ_PF_TAGLOG 11
 #endif
 #ifndef LZ_PF18_W
-#define LZ_PF18_W 9
+#define LZ_PF18_W 11
 #endif
 #ifndef LZ_PF18_NLDS
 #define LZ_PF18_NLDS 3

@@ -39,14 +39,18 @@
 #define LZ_MM_LONGOFF   16u         // MM_LONGOFF, lizard_common.h:84 (minMatchLongOff of levels 20-29/40-49)
 
 // ---- hash tables of the priceFast levels (ours; only the parse RESULT is pinned by the reference) ----
-// All hold block-relative positions; kEmpty is a value no probe position reaches, so an empty slot fails
-// "e < p" like the reference's zeroed slot fails "e >= lowLimit" and is always overwritten (:170-171).
+// What a slot tells a probe at position p is the AGE of its entry, age(p, e) = how far back the stored position lies: the
+// reference's tests (:63-65 "matchIndex < current, >= lowLimit, >= MIN_OFFSET back", :170-171 "put unless < MIN_OFFSET back")
+// are tests on the age.  A slot that was never written, or whose entry has left the 4 MiB window, is dead: its age is
+// above maxDistance, it fails every test like the reference's zeroed slot fails "e >= lowLimit", and it is always overwritten.
 // Every form carries check bits beside the position (a hash of the 4 bytes there).
+// The u32 forms keep the position modulo 2^24 and are exact for ANY block size: a sweep every 2^22 positions re-stamps the
+// slots that are dead by then as "exactly 2^23 old" (what a fresh table holds), so no age ever reaches 2^24.
 //   LzTab24c  LDS, u16 + u8 arrays: 18-bit position + 6 check bits, blocks <= 256 KiB — the benchmark configuration —
 //             48 KiB at hashLog 14: three tables per CU
-//   LzTab32   u32 slots, 24-bit position + 8 check bits, blocks < 16 MiB: in LDS (64 KiB at hashLog 14, two per CU) for
-//             the larger blocks, in a global-memory slot (one sector per access) for the waves without an LDS table and
-//             for hashLog 18 (levels 22/42)
+//   LzTab32G / LzTab32L   u32 slots, position mod 2^24 + 8 check bits, any block size: in LDS (64 KiB at hashLog 14, two per
+//             CU) for blocks above 256 KiB, in a global-memory slot (one sector per access) for the waves without an LDS
+//             table and for hashLog 18 (levels 22/42)
 #define LZ_EMPTY24 0xFFFFFFu
 #define LZ_EMPTY18 0x3FFFFu
 struct LzTab24c {
@@ -59,7 +63,10 @@ struct LzTab24c {
     LZ_DEVM static u32 make(u32 p, u32 c) { return p | (c << 18); }
     LZ_DEVM void specPut(u32 h, u32 p) const { lo[h] = (u16)p; }
     LZ_DEVM bool specLost(u32 h, u32 p) const { return lo[h] != (u16)p; }
-    LZ_DEVM u32  get(u32 h) const { return (u32)lo[h] | ((u32)hi[h] << 16); }
+    static constexpr bool kSweeps = false;                       // full positions: blocks <= 256 KiB
+    LZ_DEVM static u32 age(u32 p, u32 e) { return p - e; }       // empty (0x3FFFF, never reached by p) and nothing else wraps: dead
+    LZ_DEVM static u32 dead(u32) { return LZ_EMPTY18; }
+    LZ_DEVM u32  get(u32 h, u32) const { return (u32)lo[h] | ((u32)hi[h] << 16); }
     LZ_DEVM void set(u32 h, u32 v) const { lo[h] = (u16)v; hi[h] = (u8)(v >> 16); }
     LZ_DEVM void sync() const { lz_lds_sync(); }
 };
@@ -71,20 +78,25 @@ struct LzTab32G {                                                // slots in a g
     LZ_DEVM static u32 pos(u32 raw) { return raw & 0xFFFFFFu; }
     LZ_DEVM static u32 chk(u32 raw) { return raw >> 24; }
     LZ_DEVM static u32 chkOf(u32 first4) { return (first4 * 2654435761u) >> 24; }
-    LZ_DEVM static u32 make(u32 p, u32 c) { return p | (c << 24); }
+    LZ_DEVM static u32 make(u32 p, u32 c) { return (p & 0xFFFFFFu) | (c << 24); }
+    static constexpr bool kSweeps = true;
+    LZ_DEVM static u32 age(u32 p, u32 e) { return (p - e) & 0xFFFFFFu; }
+    LZ_DEVM static u32 dead(u32 p) { return (p - (1u << 23)) & 0xFFFFFFu; }       // 2^23 old at position p
     // Occupancy summary (LDS, optional; levels 22/42 with their 2^18 slots): as LzTabWide::occ in lz_block.h
     u32* occ = nullptr;
     u32 occShift = 0;
     LZ_DEVM void specPut(u32, u32) const {}
     LZ_DEVM bool specLost(u32, u32) const { return false; }
-    LZ_DEVM u32  get(u32 h) const
+    LZ_DEVM u32  get(u32 h, u32 p) const
     {
         if (!occ) return w[h];
         const u32 b = h >> occShift;
         const bool oc = (occ[b >> 5] >> (b & 31u)) & 1u;
         const u32 v = w[oc ? h : 0u];
-        return oc ? v : LZ_EMPTY24;
+        return oc ? v : dead(p);
     }
+    LZ_DEVM u32  raw(u32 i) const { return w[i]; }               // sweeps: the slot itself, no summary, no side effects
+    LZ_DEVM void setRaw(u32 i, u32 v) const { w[i] = v; }
     LZ_DEVM void set(u32 h, u32 v) const
     {
         w[h] = v;
@@ -99,18 +111,33 @@ struct LzTab32L {                                                // the same slo
     LZ_DEVM static u32 pos(u32 raw) { return raw & 0xFFFFFFu; }
     LZ_DEVM static u32 chk(u32 raw) { return raw >> 24; }
     LZ_DEVM static u32 chkOf(u32 first4) { return (first4 * 2654435761u) >> 24; }
-    LZ_DEVM static u32 make(u32 p, u32 c) { return p | (c << 24); }
+    LZ_DEVM static u32 make(u32 p, u32 c) { return (p & 0xFFFFFFu) | (c << 24); }
+    static constexpr bool kSweeps = true;
+    LZ_DEVM static u32 age(u32 p, u32 e) { return (p - e) & 0xFFFFFFu; }
+    LZ_DEVM static u32 dead(u32 p) { return (p - (1u << 23)) & 0xFFFFFFu; }
+    LZ_DEVM u32  raw(u32 i) const { return w[i]; }
+    LZ_DEVM void setRaw(u32 i, u32 v) const { w[i] = v; }
     // speculative put of the low half only: the position's low 16 bits tell the lanes of a round apart (they differ by < 64)
     LZ_DEVM void specPut(u32 h, u32 p) const { ((LZ_LDS u16*)w)[2u * h] = (u16)p; }
     LZ_DEVM bool specLost(u32 h, u32 p) const { return ((LZ_LDS u16*)w)[2u * h] != (u16)p; }
-    LZ_DEVM u32  get(u32 h) const { return w[h]; }
+    LZ_DEVM u32  get(u32 h, u32) const { return w[h]; }
     LZ_DEVM void set(u32 h, u32 v) const { w[h] = v; }
     LZ_DEVM void sync() const { lz_lds_sync(); }
 };
-template <int HASHLOG> LZ_DEV void lz_pf_tab_fresh(const LzTab32L& t) { for (u32 i = lz_lane(); i < (1u << HASHLOG); i += 64u) t.w[i] = LZ_EMPTY24; }
+template <int HASHLOG> LZ_DEV void lz_pf_tab_fresh(const LzTab32L& t) { for (u32 i = lz_lane(); i < (1u << HASHLOG); i += 64u) t.w[i] = LzTab32L::dead(0); }
+// Re-stamp the slots whose entry has left the window at position Ps (age > maxDistance): every 2^22 positions (blocks above 4 MiB only)
+#define LZ_PF_SWEEP_EVERY (1u << 22)
+template <int HASHLOG, class TAB>
+LZ_DEV void lz_pf_tab_sweep(const TAB& t, u32 Ps)
+{
+    for (u32 i = lz_lane(); i < (1u << HASHLOG); i += 64u) {
+        const u32 v = t.raw(i);
+        if (TAB::age(Ps, TAB::pos(v)) > (1u << 22) - 1u) t.setRaw(i, TAB::dead(Ps));
+    }
+}
 template <int HASHLOG> LZ_DEV void lz_pf_tab_fresh(const LzTab32G& t)
 {
-    for (u32 i = lz_lane(); i < (1u << HASHLOG); i += 64u) t.w[i] = LZ_EMPTY24;
+    for (u32 i = lz_lane(); i < (1u << HASHLOG); i += 64u) t.w[i] = LzTab32G::dead(0);
     if (t.occ) for (u32 i = lz_lane(); i < (((1u << HASHLOG) >> t.occShift) >> 5); i += 64u) t.occ[i] = 0u;
 }
 template <int HASHLOG> LZ_DEV void lz_pf_tab_fresh(const LzTab24c& t)
@@ -224,6 +251,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
         u32 P = 0, M = 0, ml = 0, back0 = 0;
         for (;;) {
             if (ip >= mflimit) goto tail;                        // pricefast.h:158
+            if constexpr (TAB::kSweeps) if (ip >= st.sweepAt) { table.sync(); lz_pf_tab_sweep<HASHLOG>(table, ip); st.sweepAt = ip + LZ_PF_SWEEP_EVERY; table.sync(); }
             // move the window to ip: up to 64 positions further its near half is a lane shift of what is already here and only the
             // far half is requested (it is used a round from now: by the lazy step, or as the next round's near half)
             if (ip != winBase) {
@@ -248,7 +276,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
             const u32 h = lz_hash5<HASHLOG>(bytes);
             const u32 myChk = TAB::chkOf(first4);
             u32 e, ec;                                           // pricefast.h:160,168 (old value; garbage when !valid); its check bits
-            { const u32 raw = table.get(h); e = TAB::pos(raw); ec = TAB::chk(raw); }
+            { const u32 raw = table.get(h, p); e = TAB::pos(raw); ec = TAB::chk(raw); }
             // Which lanes of this round share a table slot?  LDS tables: every lane stores the low half of its position
             // speculatively and reads the slot back — a lane that does not find its own value shares the slot with a later
             // lane (positions of a round differ by < 2^16); exact, no extra memory, settled after the winner is known.
@@ -270,7 +298,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
             const u32 eOld = e, ecOld = ec;
             u64 pend = lz_ballot(lost);
             u64 grp = laneBit;
-            const bool putAlone = e >= p || p >= e + LZ_MIN_OFFSET;      // pricefast.h:170-171 when alone in the slot
+            const bool putAlone = TAB::age(p, e) - 1u >= LZ_MIN_OFFSET - 1u;     // pricefast.h:170-171 when alone in the slot: put unless 1..7 back
             u32 tAfter = putAlone ? p : e, tcAfter = putAlone ? myChk : ec;
             while (pend) {                                       // same-slot lanes: replay the puts in lane order
                 const u32 f = lz_ctz64(pend);
@@ -283,8 +311,8 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
                     const u32 k = lz_ctz64(m), pk = ip + k;
                     const u32 ck = lz_readlane(myChk, k);
                     if (lane == k) { e = t; ec = tc; }
-                    const bool put = t >= pk || pk >= t + LZ_MIN_OFFSET;
-                    t = put ? pk : t; tc = put ? ck : tc;
+                    const bool put = TAB::age(pk, t) - 1u >= LZ_MIN_OFFSET - 1u;
+                    t = put ? TAB::pos(TAB::make(pk, 0u)) : t; tc = put ? ck : tc;
                     if (lane == k) { tAfter = t; tcAfter = tc; }
                 }
                 if (mine) grp = g;
@@ -295,7 +323,9 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
             // the hash candidate (:63-65) if its check bits agree (else the 4-byte test of :67 fails).  One batch of loads serves
             // both: the repeat candidates of the 64 lanes are contiguous, the hash candidates are few.
             const bool repCand = valid && last_off >= LZ_MIN_OFFSET && p >= last_off && p - last_off >= lowPos;
-            const bool hashCand = valid && e < p && e >= lowPos && p - e >= LZ_MIN_OFFSET && ec == myChk;
+            const u32 ageE = TAB::age(p, e);                     // e < p, e >= lowLimit, >= MIN_OFFSET back (:63-65) as tests on the age
+            const bool hashCand = valid && ageE >= LZ_MIN_OFFSET && ageE <= (p > maxDist ? maxDist : p) && ec == myChk;
+            e = p - ageE;                                        // the candidate's position in the block (meaningful for hashCand lanes)
             const bool have24 = p + 24u <= E;                    // third 8 bytes readable inside the sub-block (p + 16 <= E - 5 always)
             const u32 fc = have24 ? 16u : 0u;
             const u32 pp = valid ? p : S, rp = repCand ? p - last_off : S;
@@ -374,17 +404,17 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
                     b2 = (u64)lo | ((u64)hi << 32);
                 } else b2 = lz_ld64(src + start2);
                 const u32 h2 = lz_hash5<HASHLOG>(b2);
-                const u32 raw2 = table.get(h2);
-                const u32 e2 = TAB::pos(raw2), c2 = TAB::chk(raw2), chk2 = TAB::chkOf((u32)b2);
-                const u32 low2 = start2 > maxDist ? start2 - maxDist : 0u;
+                const u32 raw2 = table.get(h2, start2);
+                const u32 c2 = TAB::chk(raw2), chk2 = TAB::chkOf((u32)b2);
+                const u32 age2 = TAB::age(start2, TAB::pos(raw2)), e2 = start2 - age2;
                 ml2 = 0; back2 = 0;
-                if (e2 < start2 && e2 >= low2 && start2 - e2 >= LZ_MIN_OFFSET && c2 == chk2) {              // :106-110 (check bits differ: :109 fails)
+                if (age2 >= LZ_MIN_OFFSET && age2 <= (start2 > maxDist ? maxDist : start2) && c2 == chk2) {   // :106-110 (check bits differ: :109 fails)
                     u32 mlt;                                                      // 4-byte test, length and :195-201 in one round trip
                     lz_count_both(src, start2, e2, matchlimit, ip, mlt, back2);
                     if (mlt >= 4u && (mlt >= LZ_MM_LONGOFF || start2 - e2 < LZ_16BIT_OFFSET)) { ml2 = mlt; ref2 = e2; }   // :112
                 }
                 table.sync();
-                if (lane == 0 && (e2 >= start2 || start2 >= e2 + LZ_MIN_OFFSET)) table.set(h2, TAB::make(start2, chk2));   // :190-191
+                if (lane == 0 && age2 - 1u >= LZ_MIN_OFFSET - 1u) table.set(h2, TAB::make(start2, chk2));   // :190-191
                 table.sync();
             }
             LZ_PROF(st, 1);                                      // lazy re-search (table get/set, candidate, count)

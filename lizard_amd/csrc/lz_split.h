@@ -88,7 +88,7 @@ LZ_DEV void lz_split_producer(const LzSplitArgs& a, const LzSplitShared& sh, u32
         const u32 n = (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
         const u8* src = a.src + (u64)b * a.blockSize;
         const u32 cons = lz_lds_claim(sh.nextCons) % a.nCons;                  // the block's consumer
-        lz_tab_fresh<HASHLOG>(tab); st.sweepAt = 32768u;
+        lz_tab_fresh<HASHLOG>(tab); st.sweepAt = LzTab::kSweepEvery;
         lz_lds_sync();
         for (u32 pos = 0; pos < n; ) {                                           // (n >= 1: the launcher refuses empty blocks)
             const u32 part = (n - pos) < LZ_SUBBLOCK ? (n - pos) : LZ_SUBBLOCK;

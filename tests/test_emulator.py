@@ -181,3 +181,30 @@ def test_emulated_split_producers_and_consumers(level):
         outs = emul_split(part, bs, level, nprod, ncons, seed=bs + nprod)
         for i, o in enumerate(outs):
             assert o == util.oracle_compress(part[i * bs:(i + 1) * bs], level), (level, bs, nprod, ncons, i)
+
+
+def _beyond_width_case(gap, seed):
+    """X, a run of zeros, X again `gap` + 100 positions after its first copy, a tail: slots written during the first X survive
+    the run (a run inserts next to nothing) and are `gap` + 100 old — 100 modulo the table's position width — when the second X
+    probes them with the same bytes and the same check bits."""
+    x = util.datagen(600000, 0.5, 0.0, seed)
+    return x + bytes(gap + 100 - len(x)) + x + util.datagen(300000, 0.4, 0.0, seed + 1)
+
+
+def test_emulated_fast18_block_beyond_22_bit_positions():
+    """Levels 11/31 keep positions modulo 2^22 and re-stamp dead slots every 2^20 positions (LzTabWide): a block of more than
+    4 MiB must come out as the reference writes it, with and without the occupancy summary."""
+    data = _beyond_width_case(1 << 22, 5)
+    want = util.oracle_compress(data, 11)
+    for seed in (1, 3):
+        assert emul_compress(data, 11, seed) == want, seed
+
+
+@pytest.mark.parametrize("level,seeds", [(21, (1, 4)), (22, (1, 3))])
+def test_emulated_pricefast_block_beyond_24_bit_positions(level, seeds):
+    """Levels 21/22/41/42 keep positions modulo 2^24 in their u32 slots and re-stamp dead slots every 2^22 positions: a block of
+    more than 16 MiB, both residences of the table (LDS / global memory; level 22 with and without the occupancy summary)."""
+    data = _beyond_width_case(1 << 24, 9)
+    want = util.oracle_compress(data, level)
+    for seed in seeds:
+        assert emul_compress(data, level, seed) == want, (level, seed)
