@@ -92,11 +92,11 @@ enum {
 };
 
 /* 1 if `compressionLevel` (after the reference's clamp, lib/lizard_compress.c:303-308) runs on the GPU:
- * 10 (fastSmall), 11 (fast, blocks <= 4 MiB), 13..17 (hashChain, blocks <= 4 MiB), 21, 22 (priceFast, blocks
- * < 16 MiB) and their huff0 twins 30, 31, 34..38, 41, 42 — every row of Lizard_defaultParameters
- * (lib/lizard_common.h:234-284) whose parser is fastSmall, fast, hashChain or priceFast. */
+ * 10 (fastSmall), 11 (fast), 13..17 (hashChain), 21, 22 (priceFast) and their huff0 twins 30, 31, 34..38, 41, 42 — every
+ * row of Lizard_defaultParameters (lib/lizard_common.h:234-284) whose parser is fastSmall, fast, hashChain or priceFast,
+ * at every block size the reference takes (LIZARD_MAX_INPUT_SIZE, lib/lizard_compress.h:121). */
 int LizardGPU_levelSupported(int compressionLevel);
-/* Largest block (bytes) the GPU path takes at this level, 0 if the level has no GPU kernel. */
+/* Largest block (bytes) the GPU path takes at this level: LIZARD_MAX_INPUT_SIZE, or 0 if the level has no GPU kernel. */
 size_t LizardGPU_maxBlockSize(int compressionLevel);
 
 /* Devices.  The library keeps one context per device (arenas, tables, streams, pinned staging), created on first
@@ -225,8 +225,7 @@ int LizardGPU_residentWaves(void);
  * Size_t results: bytes written, or an error code that LizardGPU_frameIsError() recognises; codes are the
  * reference's (size_t)-LizardF_ERROR_* values (lib/lizard_frame_static.h:57-67).  Refused, never emulated:
  * linked-block frames larger than one block (blockMode_invalid), levels without a GPU kernel
- * (compressionLevel_invalid), block sizes above LizardGPU_maxBlockSize(level) (maxBlockSize_invalid: 4 MiB at levels
- * 11/31/13-17/34-38, 16 MiB excluded at 21/22/41/42) and skippable frames (frameType_unknown).
+ * (compressionLevel_invalid) and skippable frames (frameType_unknown).
  * ===================================================================================================== */
 typedef struct {
     unsigned           blockSizeID;          /* LizardF_blockSizeID_t: 0 = default (128 KiB), 1..7 = 128K,256K,1M,4M,16M,64M,256M */

@@ -42,6 +42,7 @@ struct Ctx {
     u8*   pfTables = nullptr;   // levels 10/30/21/41: 64 KiB per resident wave for the waves whose table is not in LDS
     u8*   hcSlots = nullptr;    // hashChain levels, allocated (and zeroed) on first use / when a larger block size arrives
     size_t hcMaxBlock = 0;
+    size_t hcNSlots = 0;
     u8*   scratch = nullptr;
     u32*  counter = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -199,6 +200,7 @@ void ctx_release(Ctx& c)
     if (c.tables) (void)hipFree(c.tables);
     if (c.pfTables) (void)hipFree(c.pfTables);
     if (c.hcSlots) (void)hipFree(c.hcSlots);
+    c.hcNSlots = 0;
     if (c.scratch) (void)hipFree(c.scratch);
     if (c.counter) (void)hipFree(c.counter);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
@@ -216,12 +218,11 @@ int clamp_level(int level)                                       // reference li
 
 // Largest block the GPU path takes at a level (0 = level not on the GPU path).  The table forms of the fast and priceFast
 // parsers keep positions modulo a power of two and sweep (lz_block.h, lz_pricefast.h): any size the reference takes
-// (lib/lizard_compress.h:121).  hashChain: 22-bit positions in its bin entries, blocks up to 4 MiB.
+// (lib/lizard_compress.h:121).  hashChain keeps full positions; its per-wave work area grows with the block (launch()).
 size_t level_max_block(int lv)
 {
     const bool hcLevel = (lv >= 13 && lv <= 17) || (lv >= 34 && lv <= 38);
-    if (lv == 10 || lv == 30 || lv == 11 || lv == 31 || lv == 21 || lv == 41 || lv == 22 || lv == 42) return (size_t)LIZARD_MAX_INPUT_SIZE;
-    if (hcLevel) return (size_t)4 << 20;
+    if (lv == 10 || lv == 30 || lv == 11 || lv == 31 || lv == 21 || lv == 41 || lv == 22 || lv == 42 || hcLevel) return (size_t)LIZARD_MAX_INPUT_SIZE;
     return 0;
 }
 
@@ -248,7 +249,7 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
     LzBatch a;
     a.src = (const u8*)d_src; a.blockSize = blockSize; a.nBlocks = (u32)nBlocks; a.lastBlockSize = (u32)lastBlockSize;
     a.dst = (u8*)d_dst; a.dstStride = dstStride; a.sizes = d_sizes; a.level = (u32)lv;
-    a.scratch = c.scratch; a.counter = c.counter; a.tables = nullptr; a.tableStride = 0;
+    a.scratch = c.scratch; a.counter = c.counter; a.tables = nullptr; a.tableStride = 0; a.tableSlots = 0xFFFFFFFFu;
     // one workgroup of W waves per CU; small batches launch only as many workgroups as they have blocks for
     const bool hcLevel = (lv >= 13 && lv <= 17) || (lv >= 34 && lv <= 38);
     const bool fastMixed = blockSize <= (4u << 20);                         // global-table waves hold 22-bit positions
@@ -263,14 +264,23 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
     else if (lv == 21 || lv == 41) W = pfSmall ? (huf ? LZ_PF18_W_HUF : LZ_PF18_W) : LZ_PF_W;
     else                           W = LZ_PF22_W;
     if (hcLevel) {
+        // per wave: bins, links, and 6 bytes + 1 bit per block position (chain, packed chain words, hit bits).  One slot per resident
+        // wave while that fits in about half of the free memory (19 GiB for 256 KiB blocks, 110 GiB for 4 MiB blocks); larger
+        // blocks get as many slots as fit and the other waves leave (lz_wave_main).
         const size_t cap = (blockSize + 65535u) & ~(size_t)65535u;
         if (!c.hcSlots || c.hcMaxBlock < cap) {
-            if (c.hcSlots) { LZ_HIP(hipDeviceSynchronize()); LZ_HIP(hipFree(c.hcSlots)); c.hcSlots = nullptr; c.hcMaxBlock = 0; }
-            const size_t bytes = (size_t)c.cus * LZ_MAX_WAVES * LZ_HC_SLOT_BYTES(cap);
-            LZ_HIP(hipMalloc((void**)&c.hcSlots, bytes));
-            c.hcMaxBlock = cap;
+            if (c.hcSlots) { LZ_HIP(hipDeviceSynchronize()); LZ_HIP(hipFree(c.hcSlots)); c.hcSlots = nullptr; c.hcMaxBlock = 0; c.hcNSlots = 0; }
+            size_t freeB = 0, totalB = 0;
+            LZ_HIP(hipMemGetInfo(&freeB, &totalB));
+            size_t budget = freeB / 2u;
+            if (budget > ((size_t)128 << 30)) budget = (size_t)128 << 30;
+            size_t nSlots = budget / LZ_HC_SLOT_BYTES(cap);
+            if (nSlots > (size_t)c.cus * LZ_MAX_WAVES) nSlots = (size_t)c.cus * LZ_MAX_WAVES;
+            if (nSlots == 0) { snprintf(t_err, sizeof t_err, "level %d: no room for a hashChain work area of %zu bytes", lv, (size_t)LZ_HC_SLOT_BYTES(cap)); return -LIZARDGPU_ERR_NOMEM; }
+            LZ_HIP(hipMalloc((void**)&c.hcSlots, nSlots * LZ_HC_SLOT_BYTES(cap)));
+            c.hcMaxBlock = cap; c.hcNSlots = nSlots;
         }
-        a.tables = c.hcSlots; a.tableStride = LZ_HC_SLOT_BYTES(c.hcMaxBlock);
+        a.tables = c.hcSlots; a.tableStride = LZ_HC_SLOT_BYTES(c.hcMaxBlock); a.tableSlots = (u32)c.hcNSlots;
     } else if (lv == 11 || lv == 31 || lv == 22 || lv == 42) {
         if (!c.tables) LZ_HIP(hipMalloc((void**)&c.tables, (size_t)c.cus * LZ_MAX_WAVES * LZ_TABWIDE_BYTES(18)));
         a.tables = c.tables; a.tableStride = LZ_TABWIDE_BYTES(18);

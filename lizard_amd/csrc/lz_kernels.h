@@ -24,6 +24,7 @@ struct LzBatch {
     u8* tables;     // per resident wave, for the waves whose hash table is not in LDS: levels 10/30/21/41 a 64 KiB slot,
                     // levels 11/31/22/42 LZ_TABWIDE_BYTES(18), hashChain levels LZ_HC_SLOT_BYTES(maxBlock)
     u64 tableStride;
+    u32 tableSlots;  // number of table slots behind `tables` (hashChain with large blocks: fewer than resident waves; the waves without one leave)
 };
 
 // Residency by construction.  LDS is what limits the number of tables in flight, and the hardware hands it out
@@ -93,10 +94,13 @@ __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
     Slice& my = lds[wave];
     const u64 slot = (u64)blockIdx.x * LZ_MAX_WAVES + wave;
     u8* scratch = a.scratch + slot * LZ_SCRATCH_BYTES;
+    // table slots are dealt out wave-index-major, so that a launch with fewer slots than waves keeps every CU busy
+    const u64 tslot = (u64)wave * gridDim.x + blockIdx.x;
+    if (tslot >= a.tableSlots) return;
     void* tableMem;
     if constexpr (NLDS == W)      tableMem = (void*)ldsTables[wave];
-    else if constexpr (NLDS == 0) tableMem = (void*)(a.tables + slot * a.tableStride);
-    else tableMem = wave < (u32)NLDS ? (void*)ldsTables[wave] : (void*)(a.tables + slot * a.tableStride);
+    else if constexpr (NLDS == 0) tableMem = (void*)(a.tables + tslot * a.tableStride);
+    else tableMem = wave < (u32)NLDS ? (void*)ldsTables[wave] : (void*)(a.tables + tslot * a.tableStride);
     const u32 tabKind = (NLDS != W && wave >= (u32)NLDS) ? LZ_TABKIND_GLOBAL : LDSKIND;
     u8* const ws = (kOwnTags && tabKind == LZ_TABKIND_GLOBAL) ? (u8*)wideTags[kOwnTags ? wave - NLDS : 0] : (u8*)my.ws;
 #ifdef LZ_LDS_PRIO

@@ -26,7 +26,7 @@ void entry_block(void* a)
 // hashChain levels keep one persistent global slot that is never cleared (as the host library does): whatever an earlier
 // block left in it (bins, links, saved head tables) must not matter.
 static u8* g_hcSlot = nullptr;
-static const size_t kHcMaxBlock = 4u << 20;
+static const size_t kHcMaxBlock = 18u << 20;
 static u8* hc_slot()
 {
     if (!g_hcSlot) { g_hcSlot = (u8*)malloc(LZ_HC_SLOT_BYTES(kHcMaxBlock)); memset(g_hcSlot, 0xB7, LZ_HC_SLOT_BYTES(kHcMaxBlock)); }

@@ -208,3 +208,9 @@ def test_emulated_pricefast_block_beyond_24_bit_positions(level, seeds):
     want = util.oracle_compress(data, level)
     for seed in seeds:
         assert emul_compress(data, level, seed) == want, (level, seed)
+
+
+def test_emulated_hashchain_block_above_4mib():
+    """hashChain keeps full positions (bins are segment-relative, heads and links absolute / distances): a 6 MiB block."""
+    data = util.datagen(6 << 20, 0.5, 0.0, 3)
+    assert emul_compress(data, 13, 1) == util.oracle_compress(data, 13)

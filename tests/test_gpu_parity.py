@@ -71,21 +71,17 @@ def test_blocks_above_4mib(L):
     """Every size the reference takes (lib/lizard_compress.h:121) at the fast and priceFast levels: their tables keep positions
     modulo 2^17 / 2^22 / 2^24 and sweep.  A 17 MiB block crosses every one of those widths; the one-block path runs a single
     wave, so the bulk of it is a run (cheap to parse) between two copies of the same data exactly one position width + 100
-    apart.  hashChain still stops at 4 MiB and refuses larger blocks loudly (return 0)."""
+    apart.  hashChain keeps full positions; its per-wave work area grows with the block."""
     data = util.datagen((5 << 20) + 123, 0.5, 0.0, 31) + bytes(300000) + util.datagen(1 << 20, 0.2, 0.0, 32)
-    for level in (10, 30, 21, 11, 22):
+    for level in (10, 30, 21, 11, 22, 13):
         out, r = gpu_compress(L, data, level)
         assert out == util.oracle_compress(data, level), level
     x = util.datagen(600000, 0.5, 0.0, 9)
     big = x + bytes((1 << 24) + 100 - len(x)) + x + util.datagen(300000, 0.4, 0.0, 10)       # 17.1 MiB
-    for level in (11, 21, 41, 22, 31, 10):
+    for level in (11, 21, 41, 22, 31, 10, 13, 36):
         out, r = gpu_compress(L, big, level)
         assert out == util.oracle_compress(big, level), level
-    for level in (13, 35):
-        out, r = gpu_compress(L, data, level)
-        assert r == 0, level
-    assert L.LizardGPU_maxBlockSize(11) == L.LizardGPU_maxBlockSize(10) == L.LizardGPU_maxBlockSize(42) == 0x7E000000
-    assert L.LizardGPU_maxBlockSize(13) == 4 << 20
+    assert L.LizardGPU_maxBlockSize(11) == L.LizardGPU_maxBlockSize(10) == L.LizardGPU_maxBlockSize(42) == L.LizardGPU_maxBlockSize(13) == 0x7E000000
 
 
 def test_frame_style_capacity(L):

@@ -112,4 +112,4 @@ def test_shutdown_and_recreate(L):
     L.LizardGPU_shutdown()
     b = api.compress_blocks(data, 131072, 11)
     assert a == b and a[0] == util.oracle_compress(data[:131072], 11)
-    assert L.LizardGPU_deviceCount() >= 1 and L.LizardGPU_maxBlockSize(11) == 4 << 20 and L.LizardGPU_maxBlockSize(12) == 0
+    assert L.LizardGPU_deviceCount() >= 1 and L.LizardGPU_maxBlockSize(11) == 0x7E000000 and L.LizardGPU_maxBlockSize(12) == 0
