@@ -716,6 +716,13 @@ int LizardGPU_decompressBlocks_host(const void* src, const uint64_t* offsets, si
     int rc = ctx_init(c);
     if (rc) return rc;
     Stage& s = c.stage[0];
+    // the offsets are input like the blocks themselves: non-decreasing, every block below 4 GiB, the slots addressable
+    for (size_t i = 0; i < nBlocks; i++) {
+        if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] > 0xFFFFFFFFull) {
+            snprintf(t_err, sizeof t_err, "bad argument (offsets[%zu..%zu] are not a block)", i, i + 1); return -LIZARDGPU_ERR_ARG;
+        }
+    }
+    if (dstStride > (size_t)-1 / nBlocks) { snprintf(t_err, sizeof t_err, "bad argument (nBlocks * dstStride overflows)"); return -LIZARDGPU_ERR_ARG; }
     const size_t inBytes = (size_t)(offsets[nBlocks] - offsets[0]);
     u64* d_off = nullptr;
     if ((rc = ensure_dev(&s.d_in, &s.d_in_cap, inBytes + 64))) return rc;
@@ -725,13 +732,18 @@ int LizardGPU_decompressBlocks_host(const void* src, const uint64_t* offsets, si
     u32* d_out = (u32*)(d_off + nBlocks + 1);
     std::vector<u64> rel(nBlocks + 1);
     for (size_t i = 0; i <= nBlocks; i++) rel[i] = offsets[i] - offsets[0];
-    LZ_HIP(hipMemcpyAsync(s.d_in, (const u8*)src + offsets[0], inBytes, hipMemcpyHostToDevice, s.stream));
-    LZ_HIP(hipMemcpyAsync(d_off, rel.data(), (nBlocks + 1) * sizeof(u64), hipMemcpyHostToDevice, s.stream));
-    if ((rc = launch_decompress(c, s.d_in, d_off, 0, nullptr, nBlocks, s.d_slots, dstStride, d_out, s.stream))) return rc;
-    LZ_HIP(hipMemcpyAsync(outSizes, d_out, nBlocks * sizeof(u32), hipMemcpyDeviceToHost, s.stream));
-    LZ_HIP(hipMemcpyAsync(dst, s.d_slots, nBlocks * dstStride, hipMemcpyDeviceToHost, s.stream));
-    LZ_HIP(hipStreamSynchronize(s.stream));
-    return 0;
+    // (`rel` and the caller's buffers are read by copies in flight: every way out of here, also a failing one, drains the stream first)
+    rc = [&]() -> int {
+        LZ_HIP(hipMemcpyAsync(s.d_in, (const u8*)src + offsets[0], inBytes, hipMemcpyHostToDevice, s.stream));
+        LZ_HIP(hipMemcpyAsync(d_off, rel.data(), (nBlocks + 1) * sizeof(u64), hipMemcpyHostToDevice, s.stream));
+        int r = launch_decompress(c, s.d_in, d_off, 0, nullptr, nBlocks, s.d_slots, dstStride, d_out, s.stream);
+        if (r) return r;
+        LZ_HIP(hipMemcpyAsync(outSizes, d_out, nBlocks * sizeof(u32), hipMemcpyDeviceToHost, s.stream));
+        LZ_HIP(hipMemcpyAsync(dst, s.d_slots, nBlocks * dstStride, hipMemcpyDeviceToHost, s.stream));
+        return 0;
+    }();
+    if (hipStreamSynchronize(s.stream) != hipSuccess && !rc) { snprintf(t_err, sizeof t_err, "hipStreamSynchronize failed"); rc = -LIZARDGPU_ERR_HIP; }
+    return rc;
 }
 
 // twin of Lizard_decompress_safe (reference lib/lizard_decompress.h:64 / lizard_decompress.c:267): one block, host buffers

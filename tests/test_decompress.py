@@ -210,3 +210,17 @@ def test_gpu_decoder_short_tail_escapes(L):
         dst = ctypes.create_string_buffer(len(plain) + 8)
         assert L.LizardGPU_decompress_safe(comp, dst, len(comp), len(plain)) == len(plain), i
         assert dst.raw[:len(plain)] == plain, i
+
+
+@pytest.mark.gpu
+def test_gpu_decoder_refuses_offsets_that_are_not_blocks(L):
+    """The offsets are input like the blocks: a decreasing pair (or a block of 4 GiB and more) is refused before anything is read."""
+    comp = util.oracle_compress(util.datagen(5000, 0.5, 0.0, 1), 10)
+    buf = np.frombuffer(comp + comp, dtype=np.uint8)
+    out = np.zeros(2 * 5000, dtype=np.uint8); sz = np.zeros(2, dtype=np.uint32)
+    for offs in ([0, len(comp), len(comp) - 1], [len(comp), 0, len(comp)], [0, 1 << 33, (1 << 33) + 5]):
+        o = np.array(offs, dtype=np.uint64)
+        assert L.LizardGPU_decompressBlocks_host(buf.ctypes.data, o.ctypes.data, 2, out.ctypes.data, 5000, sz.ctypes.data) == -3, offs
+    o = np.array([0, len(comp), 2 * len(comp)], dtype=np.uint64)
+    assert L.LizardGPU_decompressBlocks_host(buf.ctypes.data, o.ctypes.data, 2, out.ctypes.data, 5000, sz.ctypes.data) == 0
+    assert list(sz) == [5000, 5000]
