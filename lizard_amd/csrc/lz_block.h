@@ -384,7 +384,7 @@ struct LzTabWide {
     LZ_DEVM u32  age(u32 p, u32 ent) const { return (p - ent) & 0x3FFFFFu; }     // dead slots: >= 65536
     LZ_DEVM bool sameCheck(u32 a, u32 b) const { return ((a ^ b) >> 22) == 0; }
     LZ_DEVM bool lostPut(u32 h, u32 mine) const { return w[h] != mine; }
-    LZ_DEVM void sync() const { lz_wave_sync(); }
+    LZ_DEVM void sync() const { lz_table_sync(); }
 };
 #define LZ_TABWIDE_BYTES(HASHLOG) ((4u << (HASHLOG)) + 64u)
 // Re-stamp every slot that is dead at position Ps (with `fresh`: every slot), 16 bytes per lane; the occupancy summary stays

@@ -102,7 +102,7 @@ struct LzTab32G {                                                // slots in a g
         w[h] = v;
         if (occ) { const u32 b = h >> occShift; lz_lds_atomic_or(&occ[b >> 5], 1u << (b & 31u)); }
     }
-    LZ_DEVM void sync() const { lz_wave_sync(); }
+    LZ_DEVM void sync() const { lz_table_sync(); }
 };
 struct LzTab32L {                                                // the same slots in LDS
     LZ_LDS u32* w;

@@ -84,6 +84,23 @@ LZ_DEV void lz_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Ordering point between the lanes of ONE wave for a table in GLOBAL memory (lane A's put, lane B's later get of the same slot).
+// The operations of one wavefront are ordered with respect to each other by the hardware — release / acquire at wavefront scope
+// emit no instructions in the AMDGPU memory model (LLVM AMDGPUUsage, gfx90a/gfx942 memory model: "fence acq_rel, wavefront: none") —
+// so this is the compiler-only fence of lz_lds_sync(): the puts stay in flight instead of a vmcnt(0) drain, one full memory round
+// trip, behind every round's scatter and twice in every lazy step.  -DLZ_TABLE_SYNC_DRAIN=1 builds the draining form (tuning variant).
+#ifndef LZ_TABLE_SYNC_DRAIN
+#define LZ_TABLE_SYNC_DRAIN 0
+#endif
+LZ_DEV void lz_table_sync()
+{
+#if LZ_TABLE_SYNC_DRAIN
+    lz_wave_sync();
+#else
+    lz_lds_sync();
+#endif
+}
+
 // Pin a per-lane value: it must be computed HERE (the optimiser may not sink its computation into a
 // later conditional block).  Used to keep arithmetic on just-loaded data next to the counted
 // s_waitcnt of its own load batch instead of behind a later, conservative vmcnt(0).

@@ -112,6 +112,7 @@ LZ_DEV u32 lz_shfl(u32 v, u32 srcLane)
 LZ_DEV void lz_wave_sync() { lzemu::park(lzemu::OP_SYNC); }
 
 LZ_DEV void lz_lds_sync() { lzemu::park(lzemu::OP_SYNC); }
+LZ_DEV void lz_table_sync() { lzemu::park(lzemu::OP_SYNC); }
 LZ_DEV void lz_pin(u32& x) { (void)x; }
 LZ_DEV void lz_converge() { lzemu::park(lzemu::OP_SYNC); }   // all lanes must arrive together
 
