@@ -154,26 +154,33 @@ void lz_fast12_kernel(LzBatch a)
 #ifndef LZ_SPLIT_CONS_HUF
 #define LZ_SPLIT_CONS_HUF 6
 #endif
+#ifndef LZ_SPLIT_BUFS
+#define LZ_SPLIT_BUFS 2                                      // sequence buffers per producer (level 10: LDS has room for 32 mailbox words per consumer)
+#endif
+#ifndef LZ_SPLIT_BUFS_HUF
+#define LZ_SPLIT_BUFS_HUF 2
+#endif
 template <bool HUF>
 __global__ __launch_bounds__(64 * (HUF ? LZ_SPLIT_PROD_HUF + LZ_SPLIT_CONS_HUF : LZ_SPLIT_PROD + LZ_SPLIT_CONS)) void lz_fast12_split_kernel(LzBatch a)
 {
     constexpr u32 NP = HUF ? LZ_SPLIT_PROD_HUF : LZ_SPLIT_PROD, NC = HUF ? LZ_SPLIT_CONS_HUF : LZ_SPLIT_CONS;
-    static_assert(NP * LZ_SPLIT_BUFS <= LZ_SPLIT_QN, "a mailbox holds every buffer of every producer");
-    static_assert(LZ_SPLIT_ARENA_BYTES(NP, NC) <= (size_t)LZ_MAX_WAVES * LZ_SCRATCH_BYTES, "the workgroup's scratch arena");
+    constexpr u32 NB = HUF ? LZ_SPLIT_BUFS_HUF : LZ_SPLIT_BUFS, QN = NP * NB <= 32u ? 32u : 64u;
+    static_assert(NP * NB <= QN, "a mailbox holds every buffer of every producer");
+    static_assert(LZ_SPLIT_ARENA_BYTES(NP, NC, NB) <= (size_t)LZ_MAX_WAVES * LZ_SCRATCH_BYTES, "the workgroup's scratch arena");
     static_assert(NP * 4u <= LZ_SPLIT_OPS_BYTES, "one position word per producer");
     constexpr u32 kTabWords = LZ_TAB_BYTES(12) / 4u + 1u;
     __shared__ u32 tables[NP][kTabWords];
     __shared__ u64 rings[NP][LZ_SEQ_RING];
     __shared__ u32 hufWs[HUF ? NC : 1][HUF ? LZ_HUF_WS_WORDS : 1];
-    __shared__ u32 shared[LZ_SPLIT_SHARED_WORDS(NP, NC)];
+    __shared__ u32 shared[LZ_SPLIT_SHARED_WORDS(NP, NC, QN)];
     const u32 wave = lz_uniform(threadIdx.x >> 6);
     const LzSplitShared sh = lz_split_shared(shared, NP, NC);
-    if (wave == 0) lz_split_shared_init(sh, NP, NC);
+    if (wave == 0) lz_split_shared_init(sh, NP, NC, NB, QN);
     __syncthreads();
     LzSplitArgs s;
     s.src = a.src; s.blockSize = a.blockSize; s.nBlocks = a.nBlocks; s.lastBlockSize = a.lastBlockSize;
     s.dst = a.dst; s.dstStride = a.dstStride; s.sizes = a.sizes; s.level = a.level; s.counter = a.counter;
-    s.arena = a.scratch + (u64)blockIdx.x * LZ_MAX_WAVES * LZ_SCRATCH_BYTES; s.nProd = NP; s.nCons = NC;
+    s.arena = a.scratch + (u64)blockIdx.x * LZ_MAX_WAVES * LZ_SCRATCH_BYTES; s.nProd = NP; s.nCons = NC; s.nBufs = NB; s.qn = QN;
     if (wave < NP) lz_split_producer<12>(s, sh, wave, (void*)tables[wave < NP ? wave : 0], rings[wave < NP ? wave : 0]);
     else           lz_split_consumer<HUF>(s, sh, wave - NP, hufWs[HUF ? wave - NP : 0]);
 }

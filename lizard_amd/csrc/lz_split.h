@@ -5,11 +5,11 @@
 // one-wave-per-block form it sits idle while its wave encodes and entropy-codes (28 % of a level-30 wave's time, 8 % at level
 // 10); here the tables never idle, and the Huffman workspaces exist once per consumer instead of being pooled.
 //
-// Hand-over.  A producer parses sub-block after sub-block of its block into one of its LZ_SPLIT_BUFS sequence buffers in global
+// Hand-over.  A producer parses sub-block after sub-block of its block into one of its nBufs sequence buffers in global
 // memory (buffer = a 64-byte job header + the sequence list), then publishes the buffer's index in the mailbox of the consumer
 // the BLOCK was bound to when it was claimed (round robin): all sub-blocks of a block go through one mailbox, in order, so the
 // consumer knows where in dst the next sub-block starts (the container's sizes are only known after the entropy stage).  The
-// mailbox is a ring of LZ_SPLIT_QN words in LDS: producers take a ticket (one LDS atomic), write their word, the consumer polls
+// mailbox is a ring of qn words in LDS: producers take a ticket (one LDS atomic), write their word, the consumer polls
 // the word at its head.  A consumer hands a buffer back through a bit in the producer's free mask.  Everything a job needs
 // beyond the sequence list travels in the header; the waves of a workgroup share nothing else, and a producer only ever waits
 // for a free buffer, a consumer only for a job: no cycle, no deadlock.  Memory order: the header and the list are global-memory
@@ -19,24 +19,21 @@
 #pragma once
 #include "lz_block.h"
 
-#ifndef LZ_SPLIT_BUFS
-#define LZ_SPLIT_BUFS 2u                                     // sequence buffers per producer
-#endif
-#define LZ_SPLIT_QN       32u                                // mailbox words per consumer (>= producers x LZ_SPLIT_BUFS)
+// Per kernel (LzSplitArgs): nBufs = sequence buffers per producer, qn = mailbox words per consumer (a power of two >= nProd x nBufs)
 #define LZ_SPLIT_HDR      64u                                // job header bytes in front of a buffer's sequence list
 #define LZ_SPLIT_BUF_BYTES (LZ_SPLIT_HDR + LZ_SEQ_BYTES)
 #define LZ_SPLIT_OPS_BYTES 256u                              // per consumer, behind its staging areas: where each producer's current block stands in dst
 
 // LDS shared by the waves of one workgroup (zeroed by the kernel before the waves part ways, except bufFree = all free).
-// Laid out by lz_split_shared(): nextCons, prodDone, qTail[nCons], bufFree[nProd], q[nCons][LZ_SPLIT_QN].
+// Laid out by lz_split_shared(): nextCons, prodDone, qTail[nCons], bufFree[nProd], q[nCons][qn].
 struct LzSplitShared {
     u32* nextCons;                                           // round-robin binding of blocks to consumers
     u32* prodDone;                                           // producers that have left
     u32* qTail;                                              // [nCons] tickets handed out per mailbox
     u32* bufFree;                                            // [nProd] bit j: buffer j of the producer is free
-    u32* q;                                                  // [nCons][LZ_SPLIT_QN] 0 = empty, else buffer index + 1
+    u32* q;                                                  // [nCons][qn] 0 = empty, else buffer index + 1
 };
-#define LZ_SPLIT_SHARED_WORDS(nProd, nCons) (2u + (nCons) + (nProd) + (nCons) * LZ_SPLIT_QN)
+#define LZ_SPLIT_SHARED_WORDS(nProd, nCons, qn) (2u + (nCons) + (nProd) + (nCons) * (qn))
 LZ_DEV LzSplitShared lz_split_shared(u32* mem, u32 nProd, u32 nCons)
 {
     LzSplitShared sh;
@@ -44,11 +41,11 @@ LZ_DEV LzSplitShared lz_split_shared(u32* mem, u32 nProd, u32 nCons)
     return sh;
 }
 // (one wave, before the others read it: the kernel puts a workgroup barrier behind this)
-LZ_DEV void lz_split_shared_init(const LzSplitShared& sh, u32 nProd, u32 nCons)
+LZ_DEV void lz_split_shared_init(const LzSplitShared& sh, u32 nProd, u32 nCons, u32 nBufs, u32 qn)
 {
-    for (u32 i = lz_lane(); i < LZ_SPLIT_SHARED_WORDS(nProd, nCons); i += 64u) sh.nextCons[i] = 0u;
+    for (u32 i = lz_lane(); i < LZ_SPLIT_SHARED_WORDS(nProd, nCons, qn); i += 64u) sh.nextCons[i] = 0u;
     lz_lds_sync();
-    for (u32 i = lz_lane(); i < nProd; i += 64u) sh.bufFree[i] = (1u << LZ_SPLIT_BUFS) - 1u;
+    for (u32 i = lz_lane(); i < nProd; i += 64u) sh.bufFree[i] = (1u << nBufs) - 1u;
     lz_lds_sync();
 }
 
@@ -63,11 +60,12 @@ struct LzSplitArgs {
     u32* counter;                                            // device-wide block counter
     u8* arena;                                               // this workgroup's scratch: producers' buffers, then consumers' staging
     u32 nProd, nCons;
+    u32 nBufs, qn;                                           // sequence buffers per producer; mailbox words per consumer
 };
 LZ_DEV u8* lz_split_buf(const LzSplitArgs& a, u32 bufIndex) { return a.arena + (u64)bufIndex * LZ_SPLIT_BUF_BYTES; }
 #define LZ_SPLIT_CONS_BYTES (2u * LZ_SUBBLOCK_PAD + LZ_SPLIT_OPS_BYTES)
-LZ_DEV u8* lz_split_staging(const LzSplitArgs& a, u32 cons) { return a.arena + (u64)a.nProd * LZ_SPLIT_BUFS * LZ_SPLIT_BUF_BYTES + (u64)cons * LZ_SPLIT_CONS_BYTES; }
-#define LZ_SPLIT_ARENA_BYTES(nProd, nCons) ((size_t)(nProd) * LZ_SPLIT_BUFS * LZ_SPLIT_BUF_BYTES + (size_t)(nCons) * LZ_SPLIT_CONS_BYTES)
+LZ_DEV u8* lz_split_staging(const LzSplitArgs& a, u32 cons) { return a.arena + (u64)a.nProd * a.nBufs * LZ_SPLIT_BUF_BYTES + (u64)cons * LZ_SPLIT_CONS_BYTES; }
+#define LZ_SPLIT_ARENA_BYTES(nProd, nCons, nBufs) ((size_t)(nProd) * (nBufs) * LZ_SPLIT_BUF_BYTES + (size_t)(nCons) * LZ_SPLIT_CONS_BYTES)
 
 // ---- producer: claim blocks, parse their sub-blocks, publish one job per sub-block ----
 template <int HASHLOG>
@@ -101,7 +99,7 @@ LZ_DEV void lz_split_producer(const LzSplitArgs& a, const LzSplitShared& sh, u32
                 lz_sleep();
             }
             lz_lds_atomic_and(&sh.bufFree[prod], lane == 0 ? ~(1u << j) : 0xFFFFFFFFu);
-            const u32 bufIndex = prod * LZ_SPLIT_BUFS + j;
+            const u32 bufIndex = prod * a.nBufs + j;
             u8* const buf = lz_split_buf(a, bufIndex);
             st.seq = (u64*)(buf + LZ_SPLIT_HDR);
             st.nlit = st.nflags = st.noff16 = st.noff24 = 0;                      // Lizard_initBlock, lizard_compress.c:130-138
@@ -118,7 +116,7 @@ LZ_DEV void lz_split_producer(const LzSplitArgs& a, const LzSplitShared& sh, u32
             }
             lz_publish_release();                                                // header and list are written before the word that announces them
             const u32 t = lz_lds_claim(&sh.qTail[cons]);
-            if (lane == 0) lz_lds_store(&sh.q[cons * LZ_SPLIT_QN + t % LZ_SPLIT_QN], bufIndex + 1u);
+            if (lane == 0) lz_lds_store(&sh.q[cons * a.qn + (t & (a.qn - 1u))], bufIndex + 1u);
             lz_converge();
             pos += part;
         }
@@ -143,16 +141,16 @@ LZ_DEV void lz_split_consumer(const LzSplitArgs& a, const LzSplitShared& sh, u32
     u32 head = 0;                                                                // uniform
     for (;;) {
         lz_converge();
-        u32 word = lz_lds_poll_u(&sh.q[cons * LZ_SPLIT_QN + head % LZ_SPLIT_QN]);
+        u32 word = lz_lds_poll_u(&sh.q[cons * a.qn + (head & (a.qn - 1u))]);
         if (!word) {
             // nothing yet: leave once every producer has left AND the mailbox is still empty after that was seen
             if (lz_lds_poll_u(sh.prodDone) == a.nProd) {
-                word = lz_lds_poll_u(&sh.q[cons * LZ_SPLIT_QN + head % LZ_SPLIT_QN]);
+                word = lz_lds_poll_u(&sh.q[cons * a.qn + (head & (a.qn - 1u))]);
                 if (!word) break;
             } else { lz_sleep(); continue; }
         }
         lz_publish_acquire();                                                    // the header and the list behind the word
-        if (lane == 0) lz_lds_store(&sh.q[cons * LZ_SPLIT_QN + head % LZ_SPLIT_QN], 0u);
+        if (lane == 0) lz_lds_store(&sh.q[cons * a.qn + (head & (a.qn - 1u))], 0u);
         lz_converge();
         head++;
         const u32 bufIndex = word - 1u;
@@ -166,7 +164,7 @@ LZ_DEV void lz_split_consumer(const LzSplitArgs& a, const LzSplitShared& sh, u32
         u8* dst = a.dst + (u64)b * a.dstStride;
         // where this sub-block starts in dst: 1 (behind the level byte, lizard_compress.c:488) or where the block's previous
         // sub-block — handled by this consumer, from this producer — ended: kept in a word of this consumer's own scratch
-        u32* const opSlot = (u32*)(st.lit + 2u * LZ_SUBBLOCK_PAD) + bufIndex / LZ_SPLIT_BUFS;
+        u32* const opSlot = (u32*)(st.lit + 2u * LZ_SUBBLOCK_PAD) + bufIndex / a.nBufs;
         u32 op;
         if (flags & LZJ_FIRST) { if (lane == 0) dst[0] = (u8)a.level; lz_converge(); op = 1u; }
         else op = lz_uniform(lz_ld_shared_u32(opSlot));
@@ -176,6 +174,6 @@ LZ_DEV void lz_split_consumer(const LzSplitArgs& a, const LzSplitShared& sh, u32
         else if (lane == 0) lz_st_shared_u32(opSlot, op);
         lz_converge();
         lz_wave_sync();
-        lz_lds_atomic_or(&sh.bufFree[bufIndex / LZ_SPLIT_BUFS], lane == 0 ? 1u << (bufIndex % LZ_SPLIT_BUFS) : 0u);   // back to its producer
+        lz_lds_atomic_or(&sh.bufFree[bufIndex / a.nBufs], lane == 0 ? 1u << (bufIndex % a.nBufs) : 0u);   // back to its producer
     }
 }

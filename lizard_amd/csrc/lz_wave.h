@@ -85,12 +85,12 @@ LZ_DEV void lz_lds_sync()
 }
 
 // Ordering point between the lanes of ONE wave for a table in GLOBAL memory (lane A's put, lane B's later get of the same slot).
-// The operations of one wavefront are ordered with respect to each other by the hardware — release / acquire at wavefront scope
-// emit no instructions in the AMDGPU memory model (LLVM AMDGPUUsage, gfx90a/gfx942 memory model: "fence acq_rel, wavefront: none") —
-// so this is the compiler-only fence of lz_lds_sync(): the puts stay in flight instead of a vmcnt(0) drain, one full memory round
-// trip, behind every round's scatter and twice in every lazy step.  -DLZ_TABLE_SYNC_DRAIN=1 builds the draining form (tuning variant).
+// Default: the draining form (lz_wave_sync: vmcnt(0) behind the puts).  The AMDGPU memory model orders the operations of one
+// wavefront without it (LLVM AMDGPUUsage, gfx90a/gfx942: "fence acq_rel, wavefront: none"), and -DLZ_TABLE_SYNC_DRAIN=0 builds that
+// form — measured on levels 21/41/22/42/11/31 it changes nothing (46.09 vs 46.05, 29.3 vs 30.1, 37.4 vs 38.0 GB/s,
+// profiles/r03d_*: the puts are acknowledged quickly and the other waves of the SIMD fill the wait), so the conservative form stays.
 #ifndef LZ_TABLE_SYNC_DRAIN
-#define LZ_TABLE_SYNC_DRAIN 0
+#define LZ_TABLE_SYNC_DRAIN 1
 #endif
 LZ_DEV void lz_table_sync()
 {

@@ -186,7 +186,7 @@ extern "C" int emul_decompress_block(const void* src, int n, void* dst, int cap,
 // lz_fast12_split_kernel do.  Block i is src + i*blockSize (the last one lastBlockSize bytes) -> dst + i*dstStride, sizes[i].
 namespace {
 struct SplitWave { LzSplitArgs a; LzSplitShared sh; u32 wave; void* table; u64* ring; u32* hufWs; bool huf; };
-void entry_split_init(void* p) { SplitWave* w = (SplitWave*)p; lz_split_shared_init(w->sh, w->a.nProd, w->a.nCons); }
+void entry_split_init(void* p) { SplitWave* w = (SplitWave*)p; lz_split_shared_init(w->sh, w->a.nProd, w->a.nCons, w->a.nBufs, w->a.qn); }
 void entry_split(void* p)
 {
     SplitWave* w = (SplitWave*)p;
@@ -199,15 +199,16 @@ void entry_split(void* p)
 extern "C" int emul_compress_split(const void* src, int nBlocks, int blockSize, int lastBlockSize, void* dst, int dstStride,
                                    unsigned* sizes, int level, int nProd, int nCons, unsigned seed)
 {
-    if ((level != 10 && level != 30) || nProd < 1 || nCons < 1 || (u32)nProd * LZ_SPLIT_BUFS > LZ_SPLIT_QN) return -1;
+    const u32 nBufs = 2u + (seed & 1u), qn = 64u;              // odd seeds: three buffers per producer
+    if ((level != 10 && level != 30) || nProd < 1 || nCons < 1 || (u32)nProd * nBufs > qn) return -1;
     LzSplitArgs a;
     a.src = (const u8*)src; a.blockSize = (u64)blockSize; a.nBlocks = (u32)nBlocks; a.lastBlockSize = (u32)lastBlockSize;
     a.dst = (u8*)dst; a.dstStride = (u64)dstStride; a.sizes = sizes; a.level = (u32)level;
     u32 counter = 0; a.counter = &counter;
-    const size_t arenaBytes = LZ_SPLIT_ARENA_BYTES((size_t)nProd, (size_t)nCons);
+    const size_t arenaBytes = LZ_SPLIT_ARENA_BYTES((size_t)nProd, (size_t)nCons, nBufs);
     a.arena = (u8*)malloc(arenaBytes); memset(a.arena, 0xC7, arenaBytes);
-    a.nProd = (u32)nProd; a.nCons = (u32)nCons;
-    std::vector<u32> shared(LZ_SPLIT_SHARED_WORDS((u32)nProd, (u32)nCons), 0xA5A5A5A5u);
+    a.nProd = (u32)nProd; a.nCons = (u32)nCons; a.nBufs = nBufs; a.qn = qn;
+    std::vector<u32> shared(LZ_SPLIT_SHARED_WORDS((u32)nProd, (u32)nCons, qn), 0xA5A5A5A5u);
     const LzSplitShared sh = lz_split_shared(shared.data(), (u32)nProd, (u32)nCons);
     const size_t tabBytes = LZ_TAB_BYTES(12) + 64;
     std::vector<u8> tables((size_t)nProd * tabBytes, 0x5A);
