@@ -114,8 +114,11 @@ def test_stream_refusals_need_no_gpu(lib):
     assert lib.LizardGPU_compressBegin(ctx, dst, 10, ctypes.byref(util.frame_prefs(10, 1, 0, 0))) == err(11)      # header room
     assert lib.LizardGPU_compressBegin(ctx, dst, 64, ctypes.byref(util.frame_prefs(10, 1, 0, 0, block_mode=0))) == err(3)   # linked
     assert lib.LizardGPU_compressBegin(ctx, dst, 64, ctypes.byref(util.frame_prefs(12, 1, 0, 0))) == err(5)      # no GPU kernel
-    assert lib.LizardGPU_compressBegin(ctx, dst, 64, ctypes.byref(util.frame_prefs(11, 5, 0, 0))) == err(2)      # 16 MiB blocks at level 11
-    assert lib.LizardGPU_compressBegin(ctx, dst, 64, ctypes.byref(util.frame_prefs(21, 5, 0, 0))) == err(2)      # 16 MiB blocks at level 21
+    for level in (11, 21, 13):                                 # 16 MiB (and larger) frame blocks are taken at every GPU level since round 3
+        c2 = ctypes.c_void_p()
+        assert lib.LizardGPU_createCompressionContext(ctypes.byref(c2)) == 0
+        assert lib.LizardGPU_compressBegin(c2, dst, 64, ctypes.byref(util.frame_prefs(level, 7, 0, 0))) == 7
+        lib.LizardGPU_freeCompressionContext(c2)
     p = util.frame_prefs(10, 1, 0, 0)
     p.frameInfo.frameType = 1
     assert lib.LizardGPU_compressBegin(ctx, dst, 64, ctypes.byref(p)) == err(13)                                 # skippable frame
