@@ -74,12 +74,13 @@ def kernel_name(level, bs):
 
 
 def kernel_source_sha16():
-    """Hash of the device sources (every lz_*.h of lizard_amd/csrc): what a committed counter pass was measured on."""
+    """Hash of the device sources of the COMPRESS kernels (every lz_*.h of lizard_amd/csrc except the decoder lz_unpack.h and the
+    host path's compaction lz_pack.h): what a committed counter pass was measured on."""
     import hashlib
     d = os.path.join(ROOT, "lizard_amd", "csrc")
     h = hashlib.sha256()
     for f in sorted(os.listdir(d)):
-        if f.startswith("lz_") and f.endswith(".h"):
+        if f.startswith("lz_") and f.endswith(".h") and f not in ("lz_unpack.h", "lz_pack.h"):
             h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -326,6 +326,23 @@ LZ_DEV u64 lzd_win_u64(u32 wv, u32 sh)
     return r ? (lo >> r) | (hi << (64u - r)) : lo;
 }
 
+// The wave's view of the literals stream, where the length escapes (and, fastLZ4, the offsets) live: a 256-byte window, lane l
+// = bytes 4l..4l+3 from `base`, reloaded only when a read leaves it.  Bytes from nl on read as zero (the stream's last dword is
+// put together byte by byte: an escape may sit in the last 1..3 bytes of the stream, lizard_decompress_liz.h:142 only asks for
+// literalsPtr <= iend - 1).
+struct LzdWin { u32 wv; u32 base; bool valid; };
+LZ_DEV u64 lzd_win_fetch(LzdWin& w, const u8* pl, u32 nl, u32 at)               // the 8 bytes at stream offset `at` (uniform)
+{
+    if (!w.valid || at < w.base || at + 8u > w.base + 256u) {
+        const u32 wa = at + 4u * lz_lane();
+        u32 v = 0;
+        if (wa + 4u <= nl) v = lz_ld32(pl + wa);
+        else for (u32 k = 0; k < 4u; k++) if (wa + k < nl) v |= (u32)pl[wa + k] << (8u * k);
+        w.wv = v; w.base = at; w.valid = true;
+    }
+    return lzd_win_u64(w.wv, at - w.base);
+}
+
 // wave-wide copy inside global memory, n uniform; src and dst do not overlap in a way that matters (src + n <= dst or src >= dst + n
 // or the caller uses lzd_copy_match)
 LZ_DEV void lzd_copy(u8* dst, const u8* src, u32 n)
@@ -382,38 +399,23 @@ LZ_DEV u32 lz_decompress_block(const u8* in, u32 inSize, u8* out, u32 outCap, u8
         // ---- sequences ----
         u32 lp = 0, o16 = 0, o24 = 0;                            // uniform cursors into literals / off16 / off24
         u32 last_off = 0;                                        // LIZv1 repeat offset; the encoder never opens a sub-block with a repeat
+        LzdWin win; win.wv = 0; win.base = 0; win.valid = false; // (a token without an escape — most LIZv1 tokens — never touches it)
         for (u32 tbase = 0; tbase < nf; tbase += 64u) {
             const u32 cnt = nf - tbase < 64u ? nf - tbase : 64u;
             const u32 tokv = lane < cnt ? pf[tbase + lane] : 0u;  // 64 tokens per load
             for (u32 t = 0; t < cnt; t++) {
                 const u32 token = lz_readlane(tokv, t);
-                // a 256-byte window of the literals stream at lp: the escapes of this sequence (and, fastLZ4, its offset when
-                // the literal run is short) are in it
-                // (the stream's last dword is put together byte by byte: its bytes below nl count — an escape may sit in the last
-                //  1..3 bytes of the stream, lizard_decompress_liz.h:142 only asks for literalsPtr <= iend - 1)
-                u32 wv = 0;
-                {
-                    const u32 wa = lp + 4u * lane;
-                    if (wa + 4u <= nl) wv = lz_ld32(pl + wa);
-                    else for (u32 k = 0; k < 4u; k++) if (wa + k < nl) wv |= (u32)pl[wa + k] << (8u * k);
-                }
                 u32 L, ml, off, used = 0;                        // used: bytes of the window consumed before the literals
                 if (lz4) {                                       // lizard_decompress_lz4.h:41-110
                     L = token & 15u;
                     if (L == 15u) {
                         if (lp + 5u > nl) return LZD_ERR;        // :47
-                        u32 v, s; lzd_len_ext(lz_readlane(wv, 0), v, s);
+                        u32 v, s; lzd_len_ext((u32)lzd_win_fetch(win, pl, nl, lp), v, s);
                         L = v + 15u; used = s;
                     }
                     if (L > nl - lp - used || nl - lp - used - L < 2u) return LZD_ERR;
                     const u32 at = lp + used + L;                // offset, then the match-length escape
-                    u64 six;                                     // the offset and up to four escape bytes
-                    if (at + 8u <= lp + 256u && at + 8u <= nl) six = lzd_win_u64(wv, at - lp);   // inside the window
-                    else {
-                        u64 tmp = 0;
-                        for (u32 k = 0; k < 6u; k++) if (at + k < nl) tmp |= (u64)pl[at + k] << (8u * k);
-                        six = (u64)lz_uniform((u32)tmp) | ((u64)lz_uniform((u32)(tmp >> 32)) << 32);
-                    }
+                    const u64 six = lzd_win_fetch(win, pl, nl, at);  // the offset and up to four escape bytes (zeros from nl on)
                     off = (u32)six & 0xFFFFu;
                     const u32 w2 = (u32)(six >> 16);
                     ml = token >> 4;
@@ -433,7 +435,7 @@ LZ_DEV u32 lz_decompress_block(const u8* in, u32 inSize, u8* out, u32 outCap, u8
                         L = token & 7u;
                         if (L == 7u) {
                             if (lp + 1u > nl) return LZD_ERR;
-                            u32 v, s; lzd_len_ext(lz_readlane(wv, 0), v, s);
+                            u32 v, s; lzd_len_ext((u32)lzd_win_fetch(win, pl, nl, lp), v, s);
                             L = v + 7u; used = s;
                         }
                         if (used > nl - lp || L > nl - lp - used) return LZD_ERR;
@@ -448,9 +450,7 @@ LZ_DEV u32 lz_decompress_block(const u8* in, u32 inSize, u8* out, u32 outCap, u8
                         ml = (token >> 3) & 15u;
                         if (ml == 15u) {
                             if (lp + 1u > nl) return LZD_ERR;
-                            u32 tmp = 0;
-                            for (u32 k = 0; k < 4u; k++) if (lp + k < nl) tmp |= (u32)pl[lp + k] << (8u * k);
-                            u32 v, s; lzd_len_ext(lz_uniform(tmp), v, s);
+                            u32 v, s; lzd_len_ext((u32)lzd_win_fetch(win, pl, nl, lp), v, s);
                             ml = v + 15u;
                             if (s > nl - lp) return LZD_ERR;
                             lp += s;
@@ -460,7 +460,7 @@ LZ_DEV u32 lz_decompress_block(const u8* in, u32 inSize, u8* out, u32 outCap, u8
                         if (token < 31u) ml = token + 16u;       // :134-141
                         else {                                   // :142-161
                             if (lp + 1u > nl) return LZD_ERR;
-                            u32 v, s; lzd_len_ext(lz_readlane(wv, 0), v, s);
+                            u32 v, s; lzd_len_ext((u32)lzd_win_fetch(win, pl, nl, lp), v, s);
                             if (s > nl - lp) return LZD_ERR;
                             lp += s;
                             ml = v + 31u + 16u;
