@@ -34,10 +34,14 @@ def test_emulated_kernel_vs_golden(level):
         assert len(out) == g["size"] and util.sha(out) == g["sha256"], (name, level)
 
 
-@pytest.mark.parametrize("level", [10, 30, 21])
+@pytest.mark.parametrize("level", [10, 30, 21, 11, 22, 13, 36])
 def test_emulated_kernel_long_range(level):
-    """Window-edge / position-wrap adversaries and multi-MiB blocks (tests/util.corpus_long)."""
-    for name, data in util.corpus_long():
+    """Window-edge / position-wrap adversaries and multi-MiB blocks (tests/util.corpus_long): all of them at the BASELINE levels,
+    every third one (a different third per level) at one level of each other kernel family."""
+    cases = util.corpus_long()
+    if level not in (10, 30, 21):
+        cases = cases[level % 3::3]
+    for name, data in cases:
         g = GOLDEN["cases"][name]["out"][str(level)]
         out = emul_compress(data, level, seed=len(name))
         assert len(out) == g["size"] and util.sha(out) == g["sha256"], (name, level)
