@@ -1,0 +1,74 @@
+/* lizard_gpu_ctx.h — private seam between the host C layer and the HIP side (not installed; the public surface is
+ * include/lizard_amd.h).  Plain C: the per-device context the two sides share, and the thin shim the host-buffer pipeline
+ * (lizard_pipeline_host.c, C) calls into lizard_gpu.hip (kernel launches, device context).  Everything else the pipeline
+ * needs from HIP is the runtime's own C API (hip_runtime_api.h). */
+#ifndef LIZARD_GPU_CTX_H
+#define LIZARD_GPU_CTX_H
+#include <hip/hip_runtime_api.h>
+#include <pthread.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define LZ_STAGES 3                                         /* chunks in flight in the host-buffer pipeline */
+#define LZ_MAX_DEVICES 16
+
+/* One stage of the host-buffer pipeline: pinned staging on the host side, input / slot / packed buffers on the device side,
+ * its own stream.  The stages alternate so that the copies of one chunk overlap the kernels of another. */
+typedef struct LzStage {
+    hipStream_t stream;
+    hipEvent_t  k0, k1, meta, done, up;                     /* up: the chunk's input is on the device */
+    uint8_t*  h_in;     size_t h_in_cap;                    /* pinned */
+    uint8_t*  h_out;    size_t h_out_cap;                   /* pinned */
+    uint32_t* h_sizes;  uint64_t* h_offsets;  size_t h_meta_cap;   /* pinned, nBlocks (+1) */
+    uint8_t*  d_in;     size_t d_in_cap;
+    uint8_t*  d_slots;  size_t d_slots_cap;
+    uint8_t*  d_packed; size_t d_packed_cap;
+    uint32_t* d_sizes;  uint64_t* d_offsets;  size_t d_meta_cap;
+} LzStage;
+
+typedef struct LzCtx {
+    int   ready;
+    int   device;
+    int   cus;
+    uint8_t* tables;            /* levels 11/31/22/42, allocated on first use */
+    uint8_t* pfTables;          /* levels 21/41: 64 KiB per resident wave for the waves whose table is not in LDS */
+    uint8_t* hcSlots;           /* hashChain levels, allocated on first use / when a larger block size arrives */
+    size_t   hcMaxBlock, hcNSlots;
+    uint8_t* scratch;
+    uint32_t* counter;
+    hipEvent_t ev0, ev1;
+    int   timed;
+    int   laneOrderOk;          /* self-check at context creation: lanes of one DS atomic are served in lane order */
+    float hostKernelMs;         /* sum over the chunks of the last host-buffer call (< 0: last call was a device call) */
+    LzStage stage[LZ_STAGES];
+    pthread_mutex_t mu;
+} LzCtx;
+
+/* Locks the selected device's context and makes that device current for the calling thread (HIP's current device is per
+ * thread); release restores the caller's device.  rc != 0: nothing is held (the error text is set). */
+typedef struct LzGuard { LzCtx* c; int saved; int rc; } LzGuard;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+void  lzk_guard_acquire(LzGuard* g);
+void  lzk_guard_release(LzGuard* g);
+char* lzk_err(void);                                        /* the calling thread's error text, LZK_ERR_BYTES bytes */
+#define LZK_ERR_BYTES 256
+int   lzk_ctx_init(LzCtx* c);
+int   lzk_clamp_level(int level);
+/* the block kernels over nBlocks blocks resident at d_src (launcher of LizardGPU_compressBlocks_device); k0 / k1 (may be NULL)
+ * are recorded around the kernel */
+int   lzk_launch(LzCtx* c, const void* d_src, size_t nBlocks, size_t blockSize, size_t lastBlockSize, void* d_dst, size_t dstStride,
+                 uint32_t* d_sizes, int level, hipStream_t stream, hipEvent_t k0, hipEvent_t k1);
+int   lzk_launch_decompress(LzCtx* c, const void* d_src, const uint64_t* d_offsets, size_t srcStride, const uint32_t* d_srcSizes,
+                            size_t nBlocks, void* d_dst, size_t dstStride, uint32_t* d_outSizes, hipStream_t stream);
+/* exclusive scan of the record sizes + compaction of the valid bytes into d_packed (lz_pack.h); mode: LZK_PACK_* */
+void  lzk_pack_launch(const void* d_in, const void* d_slots, size_t slot, const uint32_t* d_sizes, uint64_t* d_offsets, void* d_packed,
+                      uint32_t nb, uint32_t blockSize, uint32_t lastBlockSize, int mode, hipStream_t stream);
+#define LZK_PACK_PAYLOAD 0
+#define LZK_PACK_FRAME   1
+#ifdef __cplusplus
+}
+#endif
+#endif
