@@ -237,10 +237,10 @@ __global__ __launch_bounds__(64 * LZ_WAVES_HC) void lz_hashchain_kernel(LzBatch 
 #define LZ_PF18_TAGLOG 10
 #endif
 #ifndef LZ_PF18_HUF_POOL
-#define LZ_PF18_HUF_POOL 3                 // Huffman workspaces shared by the waves of a level-41 workgroup (0 = one each: 3 LDS tables + 9)
+#define LZ_PF18_HUF_POOL 2                 // Huffman workspaces shared by the waves of a level-41 workgroup (0 = one each)
 #endif
 #ifndef LZ_PF18_W_HUF
-#define LZ_PF18_W_HUF (LZ_PF18_HUF_POOL ? 9 : 11)
+#define LZ_PF18_W_HUF 11
 #endif
 #ifndef LZ_PF18_NLDS_HUF
 #define LZ_PF18_NLDS_HUF (LZ_PF18_HUF_POOL ? 3 : 2)

@@ -28,6 +28,10 @@ validate)
   ( timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" ) | tee -a $O/summary.txt
   ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/rocprof -o bench -- python $R/bench.py --no-cpu > $R/$O/bench_under_rocprof.json 2> $R/$O/rocprof.err; echo "rocprof rc=$?" ) | tee -a $O/summary.txt
   find $O/rocprof -name "*kernel_stats.csv" -exec cp {} $O/rocprofv3_kernel_stats_bench.csv \;
+  # the headline configuration alone: its kernel's mean duration must agree with the bench line's HIP events
+  ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/rocprof_headline -o headline -- python $R/bench.py --headline-only --no-cpu > $R/$O/bench_headline_under_rocprof.json 2> $R/$O/rocprof_headline.err; echo "rocprof headline rc=$?" ) | tee -a $O/summary.txt
+  find $O/rocprof_headline -name "*kernel_stats.csv" -exec cp {} $O/rocprofv3_kernel_stats_bench_headline_only.csv \;
+  find $O/rocprof_headline -name "*.csv" -size +1M -delete; find $O/rocprof_headline -name "*.db" -delete
   find $O/rocprof -name "*.csv" -size +1M -delete; find $O/rocprof -name "*.db" -delete
   bash scripts/gpu_traffic.sh $TAG "10 262144 65536" "10 4194304 6656" "30 262144 16384" "21 262144 16384" "11 262144 16384" "13 262144 16384" > $O/traffic.log 2>&1
   grep -E "^L" $O/traffic.log | tee -a $O/summary.txt
