@@ -15,11 +15,12 @@
 //   fast.h:75-82 restarts after every match), so ONE ROUND evaluates the next 64 visits at once:
 //     lane l -> visit v0+l -> position p, 8 source bytes (loaded one round ahead), hash5, table slot.
 //   Two visits of one round can hit the same table slot; the reference would have shown the later one the
-//   earlier one's position.  Such rounds are detected without extra memory when the table is in LDS (every
-//   lane stores its entry speculatively and reads the slot back: LzTab), through a small LDS tag array when
-//   the table is in global memory (LzTabWide: nothing is stored before the winner is known); only then a
-//   short loop over the clashing hash values rebuilds, per lane, the mask of same-slot lanes, from which the
-//   in-order predecessor (and later the in-order LAST writer) follow with clz/ctz on ballot masks.
+//   earlier one's position.  With the table in LDS that order comes from the hardware: the get and the put of a
+//   round are ONE pair of returning LDS atomics, and the lanes of one DS atomic that hit the same dword are served in
+//   lane order (LzTab::xchg; the library checks that property when a device's context is created).  With the table in
+//   global memory (LzTabWide: nothing is stored before the winner is known) such rounds are found through a small LDS
+//   tag array; only then a short loop over the clashing hash values rebuilds, per lane, the mask of same-slot lanes,
+//   from which the in-order predecessor (and later the in-order LAST writer) follow with clz/ctz on ballot masks.
 //   Each lane then applies the reference's accept test to its candidate; the first accepting lane
 //   (ctz of the ballot) is the match the reference would have taken; lanes up to and including it
 //   commit their table puts, later lanes are discarded (the reference never reached them).
@@ -706,11 +707,10 @@ LZ_DEV u32 lz_write_subblock_seq(const u8* src, u32 S, u32 E, u8* op, LzStreams&
 //   LZ_TABKIND_LDS     fast parser: LZ_TAB_BYTES(HASHLOG) bytes of LDS (24-bit slots with check bits, LzTab);
 //                      priceFast: 4 << HASHLOG bytes of LDS, u32 slots = 24-bit position + 8 check bits (LzTab32L, blocks < 16 MiB)
 //   LZ_TABKIND_GLOBAL  u32 slots in global memory: fast parser LZ_TABWIDE_BYTES(HASHLOG) bytes, 16-byte aligned
-//                      (LzTabWide, blocks <= 4 MiB; the only form for HASHLOG > 14); priceFast 4 << HASHLOG bytes (LzTab32G)
+//                      (LzTabWide, any block size; the only form for HASHLOG > 14); priceFast 4 << HASHLOG bytes (LzTab32G)
 //   LZ_TABKIND_LDS18   priceFast only: LZ_TAB24C_BYTES(HASHLOG) bytes of LDS, 18-bit position + 6 check bits (LzTab24c, blocks <= 256 KiB)
 // AUX:      priceFast -> TAGLOG of the round tag array (ws holds 2^TAGLOG bytes of LDS).
-//           hashChain -> searchLength (4 or 5); tableMem = the wave's LZ_HC_SLOT_BYTES slot (global, zeroed once by
-//           the host), ws doubles as the 2^LZ_HC_TAGLOG-byte tag array.
+//           hashChain -> searchLength (4 or 5); tableMem = the wave's LZ_HC_SLOT_BYTES slot (global; nothing in it needs clearing).
 // PARSER: 0 = fastSmall/fast + fastLZ4 codewords, 1 = priceFast + LIZv1 codewords, 2 = hashChain + fastLZ4 codewords.
 #define LZ_PARSER_FAST      0
 #define LZ_PARSER_PRICEFAST 1

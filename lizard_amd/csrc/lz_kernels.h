@@ -120,10 +120,10 @@ __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
     }
 }
 
-// levels 10 / 30: fastSmall parser, 2^12-slot table + sequence ring (+ Huffman workspace).  MIXED: 16 waves, of which
-// 12 (5 with the Huffman workspaces) keep the 24-bit-slot table (12 KiB) in LDS and the others a u32-slot table
-// in global memory — full 22-bit positions there, hence blocks up to 4 MiB; larger blocks run the all-LDS form
-// (13 / 9 waves), whose 17-bit relative positions have no size limit.
+// levels 10 / 30, the one-wave-per-block form of rounds 1-2 (launched only by LZ_FAST12_SPLIT=0 builds, kept for side-by-side
+// measurements; the library runs lz_fast12_split_kernel below): fastSmall parser, 2^12-slot table + sequence ring (+ Huffman
+// workspace).  MIXED: level 10 thirteen waves with the 12 KiB table in LDS; level 30 sixteen waves, eleven with the table in LDS
+// and five with a u32-slot table in global memory; larger blocks run the all-LDS form (13 / 11 waves).
 template <bool HUF, bool MIXED>
 __global__ __launch_bounds__(64 * (MIXED ? (HUF ? LZ_WAVES_FAST_HUF : LZ_WAVES_FAST) : (HUF ? LZ_WAVES_FASTLDS_HUF : LZ_WAVES_FASTLDS)))
 void lz_fast12_kernel(LzBatch a)
@@ -207,13 +207,12 @@ __global__ __launch_bounds__(64 * LZ_WAVES_HC) void lz_hashchain_kernel(LzBatch 
     lz_wave_main<LZ_PARSER_HASHCHAIN, 18, SEARCHLEN, HUF, LZ_WAVES_HC, (HUF ? LZ_HUF_WS_WORDS : 1)>(a);
 }
 
-// levels 21 / 41: priceFast + LIZv1, 2^14-slot table.  The parse is a latency chain, so throughput follows the
-// number of resident waves, and a wave whose table is in LDS is several times faster than one that keeps it in a
-// global-memory slot (there every probe is a memory-side sector).  Two forms, chosen by block size:
-//   SMALL (blocks <= 256 KiB, the benchmark configuration): 18-bit positions packed into 36 KiB (LzTab18) — four
-//         tables per CU (two beside the sixteen 5.3 KiB Huffman workspaces of level 41);
-//   general (blocks < 16 MiB): 24-bit positions, 48 KiB (LzTabPf24) — two tables per CU (one at level 41).
-// The remaining waves of the workgroup keep u32 slots in their 64 KiB global-memory slot (LzTab32).
+// levels 21 / 41: priceFast + LIZv1, 2^14-slot table.  A wave whose table is in LDS is bound by the issue latency of its own
+// instruction chain (one exposed memory trip per sequence, lz_pricefast.h); the waves beyond the LDS's three tables keep the
+// table in a global-memory slot (every probe a 128-byte line) and fill the issue slots the LDS waves leave.  Two forms by block size:
+//   SMALL (blocks <= 256 KiB, the benchmark configuration): 18-bit position + 6 check bits, 48 KiB (LzTab24c) — three tables per CU;
+//   general (any size): u32 slots, position mod 2^24 + 8 check bits, 64 KiB (LzTab32L) — two tables per CU.
+// The remaining waves of the workgroup keep the same u32 slots in their 64 KiB global-memory slot (LzTab32G).
 #ifndef LZ_PF_W
 #define LZ_PF_W 12
 #endif
