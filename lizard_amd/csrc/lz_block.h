@@ -87,16 +87,36 @@ LZ_DEV void lz_streams_bind(LzStreams& st, u8* scratch, bool lz4Codewords, u64* 
 
 // 64-bit-build hash of the reference: hash5 over an 8-byte little-endian read
 // (reference lib/lizard_compress.c:77,90-91; chosen by lizard_parser_fastsmall.h:4-9 / fast.h:7-12).
+// ((u * prime5bytes) << 24) >> (64 - HASHLOG) is the top of u * (prime5bytes << 24): only the high word of that product is
+// needed, written out as its three partial products so that the one over the first four bytes (LZ_HASH5_KHI below) can be
+// shared with the tables' check bits (lz_check_mix) — 32-bit multiplies are quarter-rate instructions and the parse is
+// issue-bound.  The fifth byte's term is an 8 x 8-bit product.
+#define LZ_HASH5_K   (889523592379ULL << 24)
+#define LZ_HASH5_KLO ((u32)LZ_HASH5_K)                 /* 0xBB000000 */
+#define LZ_HASH5_KHI ((u32)(LZ_HASH5_K >> 32))
 template <int HASHLOG>
-LZ_DEV u32 lz_hash5(u64 u) { return (u32)(((u * 889523592379ULL) << 24) >> (64 - HASHLOG)); }
+LZ_DEV u32 lz_hash5(u64 u)
+{
+    const u32 lo = (u32)u, b4 = (u32)(u >> 32) & 0xFFu;
+    const u32 hi = lz_mulhi(lo, LZ_HASH5_KLO) + lo * LZ_HASH5_KHI + (lz_opaque(lz_mul24(b4, LZ_HASH5_KLO >> 24)) << 24);
+    return hi >> (32 - HASHLOG);
+}
+// the plain form (one 64-bit multiply = three 32-bit ones).  lz_pricefast.h keeps it: with the form above its kernels need 22
+// more VGPRs (92 -> 114, 133 -> 160) and levels 21 / 41 lose 1.3 % / 4.5 % (profiles/r03r_*)
+template <int HASHLOG>
+LZ_DEV u32 lz_hash5_plain(u64 u) { return (u32)(((u * 889523592379ULL) << 24) >> (64 - HASHLOG)); }
+// 32 mixed bits of the first four bytes at a position; the tables keep the top few as check bits beside the position.  Any
+// function of those four bytes serves (equal bytes => equal bits, fast.h:97 is the test that counts); this one costs nothing,
+// it is a partial product of the hash.
+LZ_DEV u32 lz_check_mix(u32 first4) { return first4 * LZ_HASH5_KHI; }
 
 // Offset of visit v from the run start and the step taken after it, closed form of
 // "step = searchMatchNb++ >> Lizard_skipTrigger" (reference lizard_parser_fast.h:75-82):
 // s_0 = 1, s_v = (63+v)>>6, f(v) = sum_{j<v} s_j.
 LZ_DEV u32 lz_visit_off(u32 v)
 {
-    u32 q = (v - 1u) >> 6, t = (v - 1u) & 63u;
-    return v == 0 ? 0u : 1u + 32u * q * (q + 1u) + t * (q + 1u);
+    u32 q = (v - 1u) >> 6, t = (v - 1u) & 63u;                              // offsets stay below the block size: 24-bit factors
+    return v == 0 ? 0u : 1u + lz_mul24(32u * q + t, q + 1u);
 }
 LZ_DEV u32 lz_visit_step(u32 v) { return v == 0 ? 1u : (63u + v) >> 6; }
 
@@ -317,7 +337,7 @@ struct LzTab {
         lz_lds_mskor_rtn2((LZ_LDS u32*)lo + (h >> 1), 0xFFFFu << sl, (ent & 0xFFFFu) << sl, (LZ_LDS u32*)hi + (h >> 2), 0xFFu << sh, ((ent >> 16) & 0xFFu) << sh, ol, oh);
         return ((ol >> sl) & 0xFFFFu) | (((oh >> sh) & 0xFFu) << 16);
     }
-    LZ_DEVM u32  entry(u32 p, u32 first4) const { return (p & 0x1FFFFu) | ((first4 * 2654435761u) >> 25 << 17); }
+    LZ_DEVM u32  entry(u32 p, u32 first4) const { return (p & 0x1FFFFu) | (lz_check_mix(first4) >> 25 << 17); }
     LZ_DEVM u32  get(u32 h) const { return (u32)lo[h] | ((u32)hi[h] << 16); }
     LZ_DEVM u32  get(u32 h, u32) const { return get(h); }
     LZ_DEVM void set(u32 h, u32 ent) const { lo[h] = (u16)ent; hi[h] = (u8)(ent >> 16); }
@@ -368,7 +388,7 @@ struct LzTabWide {
     static constexpr bool kXchg = false;
     LZ_DEVM u32 xchg(u32, u32) const { return 0; }
     LZ_DEVM static u32 dead(u32 p) { return (p - (1u << 21)) & 0x3FFFFFu; }      // a slot value that is 2^21 old at position p
-    LZ_DEVM u32  entry(u32 p, u32 first4) const { return (p & 0x3FFFFFu) | ((first4 * 2654435761u) >> 22 << 22); }
+    LZ_DEVM u32  entry(u32 p, u32 first4) const { return (p & 0x3FFFFFu) | (lz_check_mix(first4) >> 22 << 22); }
     LZ_DEVM u32  get(u32 h, u32 p) const
     {
         if (!occ) return w[h];
@@ -421,6 +441,15 @@ LZ_DEV void lz_slot_pos(u32 ip, u32 special, u32 slot, u32 mflimit, u32& p, bool
     putOnly = post && slot == 0;
 }
 
+// Backward extension of a winner (fast.h:102) from the bytes its lane fetched: cb = equal bytes in the 8 before position and
+// candidate (0 when the candidate starts less than 8 bytes into the block: nothing was fetched).  Exact when the run ends inside
+// those bytes or at the limit (anchor, start of the block), else 0xFFFF = unresolved (lz_count_back finishes it).  Wave-uniform.
+LZ_DEV u32 lz_back_from(u32 cb, u32 P, u32 M, u32 anchor)
+{
+    const u32 roomB = (P - anchor) < M ? (P - anchor) : M;
+    return (roomB <= cb || (M >= 8u && cb < 8u)) ? (cb < roomB ? cb : roomB) : 0xFFFFu;
+}
+
 // Memory-latency structure of a round (the parse is latency-bound: ~70 % of wave time is s_waitcnt):
 //   * the 8 source bytes of every lane are loaded ONE ROUND AHEAD (nextBytes), for the slots the run
 //     will reach if the current round finds no match, and right after a match for the first round of
@@ -428,9 +457,32 @@ LZ_DEV void lz_slot_pos(u32 ip, u32 special, u32 slot, u32 mflimit, u32& p, bool
 //   * lanes whose candidate survives the check bits fetch, in one batch, everything the winner needs:
 //     16 bytes forward at candidate and position (resolves match lengths < 16 without another trip)
 //     and 8 bytes backward (resolves backward extensions < 8).
+//
+// Round width.  With a table in LDS a probe costs nothing and every round takes all 64 slots.  With a table in global memory
+// (LzTabWide) every probed slot is a random 128-byte line, and the slots behind the round's winner are probed for nothing —
+// the winner is lane 13 on average on the bench data, two thirds of a round's lines.  Those runs start LZ_WIDE_W0 slots wide
+// and double the width after every round without a winner; which slots a round covers changes nothing in what is committed.
+#ifndef LZ_WIDE_W0
+#define LZ_WIDE_W0 16u
+#endif
+//
+// More than one sequence per round (LDS tables).  A round costs an LDS trip and, with a candidate, a memory trip; the wave waits
+// through both.  In the first round of a run the lanes behind the winner hold the consecutive positions P+1, P+2, ... and have
+// already exchanged their entries and fetched their candidates' bytes.  When the winner's lengths are known from its batch, the
+// reference's next steps are all in those lanes: put(ip-2), the probe of ip (fast.h:146-165) and the visits ip+1, ip+2, ... of the
+// next run (step 1 for 64 visits) — provided none of them found in its slot the put of a lane in between, i.e. of a position
+// inside the match, which the reference never inserts.  Positions written in this round are recognised by their age, so that test
+// is one comparison per lane.  If it holds up to the next accepting lane, the first sequence is pushed and the round goes on with
+// that lane as its winner; the lanes inside the match are taken back like the lanes behind the last winner.
+#ifndef LZ_FAST_CHAIN
+#define LZ_FAST_CHAIN 1
+#endif
 template <int HASHLOG, class TAB>
 LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStreams& st)
 {
+    constexpr bool kChain = TAB::kXchg && LZ_FAST_CHAIN;             // several sequences out of one round (see below)
+    constexpr bool kNarrow = TAB::kTagDedup && LZ_WIDE_W0 < 64u;
+    constexpr u32  kW0 = kNarrow ? LZ_WIDE_W0 : 64u;
     const u32 lane = lz_lane();
     const u64 laneBit = 1ull << lane;
     const u64 lanesBelow = laneBit - 1ull;
@@ -452,7 +504,9 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
     u32 pNext; bool validNext, putOnlyNext;
     u64 nextBytes;
     lz_slot_pos(ip, 0u, lane, mflimit, pNext, validNext, putOnlyNext);
+    if constexpr (kNarrow) validNext = validNext && lane < kW0;
     nextBytes = lz_ld64(src + (validNext ? pNext : S));
+    u32 W = kW0;            // uniform: slots of the round about to run
     for (;;) {
         // ---------------- search: rounds of 64 slots until a lane accepts ----------------
         u32 v0 = 0;         // uniform: slots consumed by earlier rounds of this run
@@ -463,7 +517,8 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
             const u64 bytes = nextBytes;
             u32 pAhead;                                                  // my slot's position in the next round of this run
             {
-                lz_slot_pos(ip, special, v0 + 64u + lane, mflimit, pAhead, validNext, putOnlyNext);
+                lz_slot_pos(ip, special, v0 + W + lane, mflimit, pAhead, validNext, putOnlyNext);
+                if constexpr (kNarrow) validNext = validNext && lane < (W < 32u ? 2u * W : 64u);
                 pNext = pAhead;
                 if (!validNext) pAhead = S;                              // any readable address
             }
@@ -522,7 +577,7 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
             const u32 ep = p - age;
             const bool cand = valid && !putOnly && table.sameCheck(e, mine) && age >= LZ_MIN_OFFSET && age <= LZ_MAX_DIST_LZ4
                            && age <= p - lowPos;
-            u64 cA = 0, cB = 0, pB = 0, cC = 0, pC = 0, cZ = 0, pZ = 0;
+            u64 cA = LZ_ANY64, cB = LZ_ANY64, pB = LZ_ANY64, cC = LZ_ANY64, pC = LZ_ANY64, cZ = LZ_ANY64, pZ = LZ_ANY64;   // (read by `cand` lanes only)
             const bool haveBack = cand && ep >= 8u;                      // then p >= 16 as well
             const bool have24 = p + 24u <= E;                            // third 8 bytes readable inside the sub-block
             if (cand) {                                                  // one batch, straight-line (p + 16 <= E - 5)
@@ -539,7 +594,7 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
             // match lengths from the batch, already clamped like the reference's counts (fast.h:100,102):
             // exact when the difference (or the limit) lies inside the fetched bytes, else 0xFFFF = unresolved
             bool ok = false;
-            u32 fwd = 0xFFFFu, bwd = 0xFFFFu;
+            u32 fwd = 0xFFFFu, cbk = 0u;
 #ifdef LZ_SKIP_NOCAND
             if (lz_ballot(cand))                                         // most rounds have no candidate at all: no batch, nothing to measure
 #endif
@@ -550,23 +605,49 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
                 const u32 common = x ? lz_ctz64(x) >> 3 : y ? 8u + (lz_ctz64(y) >> 3) : (have24 && y2) ? 16u + (lz_ctz64(y2) >> 3) : seen;
                 const u32 room = matchlimit - p;                         // p < matchlimit for every valid slot
                 if (common < seen || room <= seen) fwd = common < room ? common : room;
-                const u32 roomB = (p - anchor) < ep ? (p - anchor) : ep;
-                const u32 cb = !haveBack ? 0u : z ? lz_clz64(z) >> 3 : 8u;
-                if (roomB <= cb || (haveBack && cb < 8u)) bwd = cb < roomB ? cb : roomB;
+                cbk = !haveBack ? 0u : z ? lz_clz64(z) >> 3 : 8u;        // (lz_back_from turns it into the winner's backward length)
             }
-            lz_pin(fwd); lz_pin(bwd);                                    // computed here, under this batch's counted wait
+            lz_pin(fwd); lz_pin(cbk);                                    // computed here, under this batch's counted wait
             const u64 okMask = lz_ballot(ok);                            // uniform
             const u64 validMask = lz_ballot(valid);                      // uniform, a prefix of lanes
             u32 w = 0;
             u64 commit = validMask;
-            if (okMask) { w = lz_ctz64(okMask); commit = validMask & (~0ull >> (63u - w)); }
+            u64 deadMask = 0;                                            // lanes inside the matches of chained sequences
+            if (okMask) {
+                w = lz_ctz64(okMask); commit = validMask & (~0ull >> (63u - w));
+                if constexpr (kChain) {
+                    while (v0 == 0) {                                    // first round of a run: consecutive positions behind the winner
+                        const u32 Pw = lz_readlane(p, w), fw = lz_readlane(fwd, w);
+                        if (fw == 0xFFFFu) break;
+                        const u32 Mw = lz_readlane(ep, w);
+                        const u32 bk = lz_back_from(lz_readlane(cbk, w), Pw, Mw, anchor);
+                        if (bk == 0xFFFFu) break;
+                        const u32 ipn = Pw + fw, l1 = w + fw;            // fast.h:141: ip behind the sequence, and its lane
+                        if (ipn > mflimit || l1 > 63u) break;
+                        const u64 from1 = ~0ull << l1;
+                        const u64 ok2 = okMask & from1;
+                        if (!ok2) break;
+                        const u32 w2 = lz_ctz64(ok2);                    // the next accepting lane: probe of ip or a visit of the next run
+                        const u64 put2 = 1ull << (l1 - 2u);              // put(ip-2), fast.h:146
+                        const u64 dead2 = deadMask | ((from1 ^ (~0ull << (w + 1u))) & ~put2);
+                        const u64 readers = put2 | (from1 & (~0ull >> (63u - w2)));
+                        // my slot's entry was written by the lane `age` below me (consecutive positions): a put that never happened?
+                        const bool stale = age <= lane && ((dead2 >> (lane - age)) & 1ull);
+                        if (lz_ballot(stale) & readers) break;
+                        lz_seq_push(st, Pw - bk - anchor, fw + bk, Pw - Mw);      // fast.h:138
+                        anchor = ipn;
+                        deadMask = dead2; commit |= readers; w = w2;
+                    }
+                }
+            }
             // settle the table slots: slots after the winner never happened (the reference stopped there)
             if constexpr (TAB::kXchg) {
                 // Of the undone lanes on one slot, the lowest one holds in `e` what the slot must go back to (the entry of the last
                 // lane that did happen, or the value from before the round); it is the one whose `e` was not written by an undone
                 // lane: entries of this round are told from older ones by their age (positions of a round ascend).
                 const u32 pw = okMask ? lz_readlane(p, w) : 0u;
-                const bool restore = okMask != 0 && valid && !(commit & laneBit) && table.age(p, e) >= p - pw;
+                const bool eUndone = (p > pw && age < p - pw) || (kChain && age <= lane && ((deadMask >> (lane - age)) & 1ull));
+                const bool restore = okMask != 0 && valid && !(commit & laneBit) && !eUndone;
                 table.set(restore ? h : (1u << HASHLOG), e);
             } else if constexpr (TAB::kTagDedup) {                       // last committed slot of every group stores, once
                 const u64 c = grp & commit;
@@ -583,11 +664,12 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
             LZ_PROF(st, 1);                                              // round part B: candidate wait, ballots, slot settle
             if (okMask) {
                 P = lz_readlane(p, w); M = lz_readlane(ep, w);
-                ml = lz_readlane(fwd, w); back = lz_readlane(bwd, w);
+                ml = lz_readlane(fwd, w); back = lz_back_from(lz_readlane(cbk, w), P, M, anchor);
                 break;
             }
-            if (validMask != ~0ull) goto tail;                           // ran into mflimit without a match
-            v0 += 64u;
+            if (validMask != (kNarrow ? ~0ull >> (64u - W) : ~0ull)) goto tail;      // ran into mflimit without a match
+            v0 += W;
+            if constexpr (kNarrow) W = W < 32u ? 2u * W : 64u;
         }
         // ---------------- extend ----------------
         if (ml == 0xFFFFu) ml = 4u + lz_count_fwd(src, P + 4u, M + 4u, matchlimit);            // fast.h:100
@@ -601,6 +683,7 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
         // a loop-carried value makes every round's wait a vmcnt(0).)
         special = 1u;
         lz_slot_pos(ip, 1u, lane, mflimit, pNext, validNext, putOnlyNext);
+        if constexpr (kNarrow) { W = kW0; validNext = validNext && lane < kW0; }
         if (ip > mflimit) validNext = false;                             // (fast.h:143: there is no next run; any readable address)
         nextBytes = lz_ld64(src + (validNext ? pNext : S));
         lz_seq_push(st, P - anchor, ml, P - M);                          // fast.h:138 (encoded later, in parallel)

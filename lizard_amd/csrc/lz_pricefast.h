@@ -228,6 +228,9 @@ LZ_DEV void lz_encode_lizv1(const u8* src, u32 S, const LzStreams& st, u8* litOu
 // (lizard_common.h:249-250).  table: 2^HASHLOG slots (TAB::kEmpty = never written); tag: 2^TAGLOG bytes of LDS (global tables only).
 // Positions must stay below TAB::kEmpty (the launcher picks the table form by block size).
 #define LZ_PF_UNRESOLVED 0xFFFFu
+#ifndef LZ_PF_W0
+#define LZ_PF_W0 32u
+#endif
 template <int HASHLOG, int TAGLOG, class TAB>
 LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8* tag, LzStreams& st)
 {
@@ -241,6 +244,10 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
     if (E - S < LZ_MFLIMIT + 1u) { st.lastLits = E - S; st.nlit += E - S; return; }
     const u32 mflimit = E - LZ_MFLIMIT, matchlimit = E - LZ_LASTLITERALS;
     u32 ip = S + 1u;                                             // uniform, pricefast.h:155
+    // Round width (see lz_parse_fast): rounds over a table in global memory start LZ_PF_W0 positions wide after a match and
+    // double after every round without a winner — the positions behind a winner are 128-byte lines fetched for nothing.
+    constexpr bool kNarrow = !TAB::kSpecPut && LZ_PF_W0 < 64u;
+    u32 W = kNarrow ? LZ_PF_W0 : 64u;                            // uniform
     // Register window over the source: wA = the 8 bytes at winBase + lane, wB = at winBase + 64 + lane (positions from mflimit
     // on are never probed; their lanes hold the bytes at S).  A round probes winBase + lane, i.e. wA.
     u32 winBase = ip;                                            // uniform
@@ -269,14 +276,15 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
                 winBase = ip;
             }
             const u32 p = ip + lane;
-            const bool valid = p < mflimit;
+            const bool valid = p < mflimit && (!kNarrow || lane < W);
             const u32 lowPos = p > maxDist ? p - maxDist : 0u;   // pricefast.h:11-13, per probe
             const u64 bytes = wA;
             const u32 first4 = (u32)bytes;
-            const u32 h = lz_hash5<HASHLOG>(bytes);
+            const u32 h = lz_hash5_plain<HASHLOG>(bytes);
             const u32 myChk = TAB::chkOf(first4);
             u32 e, ec;                                           // pricefast.h:160,168 (old value; garbage when !valid); its check bits
-            { const u32 raw = table.get(h, p); e = TAB::pos(raw); ec = TAB::chk(raw); }
+            // (the lanes beyond a narrow round's width all read slot 0: one line instead of one each)
+            { const u32 raw = table.get(kNarrow && !valid ? 0u : h, p); e = TAB::pos(raw); ec = TAB::chk(raw); }
             // Which lanes of this round share a table slot?  LDS tables: every lane stores the low half of its position
             // speculatively and reads the slot back — a lane that does not find its own value shares the slot with a later
             // lane (positions of a round differ by < 2^16); exact, no extra memory, settled after the winner is known.
@@ -380,7 +388,9 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
                 break;
             }
             ip += lz_popc64(validMask);                          // "ip++" for every probed position, :173
+            if constexpr (kNarrow) W = W < 32u ? 2u * W : 64u;
         }
+        if constexpr (kNarrow) W = LZ_PF_W0;
         // ---------------- winner: lengths, lazy re-search, sequence push ----------------
         LZ_PROF(st, 0);                                          // search rounds
         {
@@ -403,7 +413,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
                     const u32 hi = i2 < 64u ? lz_readlane((u32)(wA >> 32), i2 & 63u) : lz_readlane((u32)(wB >> 32), i2 & 63u);
                     b2 = (u64)lo | ((u64)hi << 32);
                 } else b2 = lz_ld64(src + start2);
-                const u32 h2 = lz_hash5<HASHLOG>(b2);
+                const u32 h2 = lz_hash5_plain<HASHLOG>(b2);
                 const u32 raw2 = table.get(h2, start2);
                 const u32 c2 = TAB::chk(raw2), chk2 = TAB::chkOf((u32)b2);
                 const u32 age2 = TAB::age(start2, TAB::pos(raw2)), e2 = start2 - age2;

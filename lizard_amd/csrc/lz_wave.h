@@ -35,6 +35,7 @@ LZ_DEV u64 lz_ballot(bool pred) { return __ballot(pred); }
 
 // value of `v` in lane `src` where `src` is wave-uniform: v_readlane_b32, result is scalar
 LZ_DEV u32 lz_readlane(u32 v, u32 src) { return (u32)__builtin_amdgcn_readlane((int)v, (int)src); }
+LZ_DEV u64 lz_readlane64(u64 v, u32 src) { return (u64)lz_readlane((u32)v, src) | ((u64)lz_readlane((u32)(v >> 32), src) << 32); }
 
 // value held by the first active lane, as a scalar.  Used to pin wave-uniform state into SGPRs.
 LZ_DEV u32 lz_uniform(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
@@ -105,6 +106,15 @@ LZ_DEV void lz_table_sync()
 // later conditional block).  Used to keep arithmetic on just-loaded data next to the counted
 // s_waitcnt of its own load batch instead of behind a later, conservative vmcnt(0).
 LZ_DEV void lz_pin(u32& x) { asm volatile("" : "+v"(x)); }
+// product of two values below 2^24: one full-rate v_mul_u32_u24 (v_mul_lo_u32 is a quarter-rate instruction)
+LZ_DEV u32 lz_mul24(u32 a, u32 b) { return (u32)__umul24(a, b); }
+// keeps the optimiser from folding a cheap form back into the expensive one it was written to avoid
+LZ_DEV u32 lz_opaque(u32 x) { asm("" : "+v"(x)); return x; }
+LZ_DEV u32 lz_mulhi(u32 a, u32 b) { return __umulhi(a, b); }
+// initial value of a register that only the lanes which later assign it ever read: some valid value, whatever the register
+// holds — no fill instruction on the device (the emulator's lanes hold 0)
+LZ_DEV u64 lz_any64() { u64 x; asm volatile("" : "=v"(x)); return x; }
+#define LZ_ANY64 lz_any64()
 
 LZ_DEV u32 lz_ctz64(u64 m) { return (u32)__builtin_ctzll(m); }         // m != 0
 LZ_DEV u32 lz_clz64(u64 m) { return (u32)__builtin_clzll(m); }         // m != 0

@@ -89,6 +89,7 @@ LZ_DEV u32 lz_readlane(u32 v, u32 src)
     lzemu::park(lzemu::OP_READLANE);
     return (u32)w->res[me];
 }
+LZ_DEV u64 lz_readlane64(u64 v, u32 src) { return (u64)lz_readlane((u32)v, src) | ((u64)lz_readlane((u32)(v >> 32), src) << 32); }
 
 LZ_DEV u32 lz_uniform(u32 v)
 {
@@ -114,6 +115,10 @@ LZ_DEV void lz_wave_sync() { lzemu::park(lzemu::OP_SYNC); }
 LZ_DEV void lz_lds_sync() { lzemu::park(lzemu::OP_SYNC); }
 LZ_DEV void lz_table_sync() { lzemu::park(lzemu::OP_SYNC); }
 LZ_DEV void lz_pin(u32& x) { (void)x; }
+LZ_DEV u32 lz_mul24(u32 a, u32 b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+LZ_DEV u32 lz_opaque(u32 x) { return x; }
+LZ_DEV u32 lz_mulhi(u32 a, u32 b) { return (u32)(((u64)a * b) >> 32); }
+#define LZ_ANY64 ((u64)0)
 LZ_DEV void lz_converge() { lzemu::park(lzemu::OP_SYNC); }   // all lanes must arrive together
 
 LZ_DEV u32 lz_ctz64(u64 m) { return (u32)__builtin_ctzll(m); }
