@@ -462,25 +462,33 @@ LZ_DEV u32 lz_back_from(u32 cb, u32 P, u32 M, u32 anchor)
 // (LzTabWide) every probed slot is a random 128-byte line, and the slots behind the round's winner are probed for nothing —
 // the winner is lane 13 on average on the bench data, two thirds of a round's lines.  Those runs start LZ_WIDE_W0 slots wide
 // and double the width after every round without a winner; which slots a round covers changes nothing in what is committed.
+// (Level 11: 2.75e9 -> 1.63e9 line reads per 4 GiB at width 16, 38 -> 41 GB/s; 32 is the better start once rounds chain, below.)
 #ifndef LZ_WIDE_W0
-#define LZ_WIDE_W0 16u
+#define LZ_WIDE_W0 32u
 #endif
 //
-// More than one sequence per round (LDS tables).  A round costs an LDS trip and, with a candidate, a memory trip; the wave waits
-// through both.  In the first round of a run the lanes behind the winner hold the consecutive positions P+1, P+2, ... and have
+// More than one sequence per round.  A round costs a table trip and, with a candidate, a memory trip into the 64 KiB behind the
+// position (L2 holds 8 KiB per resident wave: those are fabric trips); the wave waits through both, and that — not the
+// instruction count — is what a round costs (profiles/r03r_w_*: 60 vector instructions fewer per round changed nothing).  In the first round of a run the lanes behind the winner hold the consecutive positions P+1, P+2, ... and have
 // already exchanged their entries and fetched their candidates' bytes.  When the winner's lengths are known from its batch, the
 // reference's next steps are all in those lanes: put(ip-2), the probe of ip (fast.h:146-165) and the visits ip+1, ip+2, ... of the
 // next run (step 1 for 64 visits) — provided none of them found in its slot the put of a lane in between, i.e. of a position
 // inside the match, which the reference never inserts.  Positions written in this round are recognised by their age, so that test
-// is one comparison per lane.  If it holds up to the next accepting lane, the first sequence is pushed and the round goes on with
-// that lane as its winner; the lanes inside the match are taken back like the lanes behind the last winner.
+// is one comparison per lane (global-memory tables store nothing before the round is settled: there a lane's entry came from
+// another lane's registers, and the test is whether that lane lies inside the match).  If it holds up to the next accepting
+// lane, the first sequence is pushed and the round goes on with that lane as its winner; the lanes inside the match are taken
+// back like the lanes behind the last winner.  On the bench data 30 % of the sequences come out of a round that already
+// produced one (2 387 rounds per 256 KiB block instead of 3 046): level 10 172 -> 199 GB/s, level 30 134 -> 151
+// (profiles/r03y_*).  Measured and not kept (profiles/r03z_*): going on INSIDE the next run when no further lane accepts (the next
+// round then starts in the schedule's step-2 stretch and can chain nothing: -2..4 %), and serving the next run's first bytes out
+// of a 128-position register window instead of a load (-3 %: that load hits L1/L2, four lane shifts cost more).
 #ifndef LZ_FAST_CHAIN
 #define LZ_FAST_CHAIN 1
 #endif
 template <int HASHLOG, class TAB>
 LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStreams& st)
 {
-    constexpr bool kChain = TAB::kXchg && LZ_FAST_CHAIN;             // several sequences out of one round (see below)
+    constexpr bool kChain = (TAB::kXchg || TAB::kTagDedup) && LZ_FAST_CHAIN;   // several sequences out of one round (see below)
     constexpr bool kNarrow = TAB::kTagDedup && LZ_WIDE_W0 < 64u;
     constexpr u32  kW0 = kNarrow ? LZ_WIDE_W0 : 64u;
     const u32 lane = lz_lane();
@@ -534,6 +542,7 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
             u32 e;                                                       // fast.h:86: the slot as this visit finds it
             u64 grp = laneBit;                                           // lanes of this round on my table slot (not needed with kXchg)
             u32 eOld = 0;
+            u32 jPrev = 64u;                                             // kTagDedup: the lane my `e` came from (64 = the table)
             if constexpr (TAB::kXchg) {
                 // fast.h:86-88 for all 64 visits in one LDS trip: every lane exchanges its entry into its slot; lanes that share a
                 // slot are served in lane order, so each gets back what the reference's serial walk would have found there.
@@ -569,7 +578,7 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
                 const u64 prev = grp & lanesBelow;
                 const u32 j = prev ? 63u - lz_clz64(prev) : lane;
                 const u32 ej = lz_shfl(mine, j);
-                if (prev) e = ej;
+                if (prev) { e = ej; jPrev = j; }
             }
             }
             // accept test, fast.h:90-97 (check bits first: they decide whether any bytes are fetched)
@@ -632,7 +641,8 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
                         const u64 dead2 = deadMask | ((from1 ^ (~0ull << (w + 1u))) & ~put2);
                         const u64 readers = put2 | (from1 & (~0ull >> (63u - w2)));
                         // my slot's entry was written by the lane `age` below me (consecutive positions): a put that never happened?
-                        const bool stale = age <= lane && ((dead2 >> (lane - age)) & 1ull);
+                        // (global tables: nothing was stored yet, the entry came from that lane's registers)
+                        const bool stale = TAB::kXchg ? (age <= lane && ((dead2 >> (lane - age)) & 1ull)) : (jPrev < 64u && ((dead2 >> jPrev) & 1ull));
                         if (lz_ballot(stale) & readers) break;
                         lz_seq_push(st, Pw - bk - anchor, fw + bk, Pw - Mw);      // fast.h:138
                         anchor = ipn;
