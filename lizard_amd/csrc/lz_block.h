@@ -684,6 +684,17 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
         // ---------------- extend ----------------
         if (ml == 0xFFFFu) ml = 4u + lz_count_fwd(src, P + 4u, M + 4u, matchlimit);            // fast.h:100
         if (back == 0xFFFFu) back = lz_count_back(src, P, M, anchor);                           // fast.h:102
+        if constexpr (TAB::kSweeps) {
+            // A match moves ip by up to a sub-block at once (128 KiB - 1), four sweep intervals of the 17-bit table, and the round's
+            // own check below only sweeps once, at the position it finds itself at: a slot stamped "65536 old" by the last sweep would
+            // by then be more than 2^17 old and read as young again.  Nothing is inserted inside a match, so the sweeps that fall due on
+            // the way are made up here, at the positions they were due (never below the winner's: every entry in the table is older).
+            const u32 ipn = P + ml;
+            while (ipn >= st.sweepAt) {
+                const u32 q = st.sweepAt > P ? st.sweepAt : P + 1u;
+                lz_tab_sweep<HASHLOG>(table, q, false); st.sweepAt = q + TAB::kSweepEvery; table.sync();
+            }
+        }
         P -= back; M -= back; ml += back;
         ip = P + ml;
         LZ_PROF(st, 2);                                                  // extension

@@ -236,3 +236,24 @@ def test_emulated_chained_rounds_on_generator_data():
         data = buf.raw
         for level in (10, 30, 11, 31):
             assert emul_compress(data, level, seed=case + 1) == util.oracle_compress(data, level), (case, P, size, level)
+
+
+def _long_match_case(prefix, run, seed):
+    """noise | one long run of zeros (a single match of `run` - 8 bytes: ip jumps across several sweep intervals of the 17-bit LDS
+    table at once) | short records "k 0 0 0 0 k'": their first four bytes equal those inside the run, their five-byte hash names a
+    slot nobody wrote.  A slot stamped "dead" by the sweep before the jump must still read as dead behind it."""
+    import random
+    rng = random.Random(seed)
+    tail = b"".join(bytes([1 + i]) + b"\0\0\0\0" + bytes([100 + i]) + rng.randbytes(10) for i in range(50))
+    return rng.randbytes(prefix) + b"\0" * run + tail
+
+
+@pytest.mark.parametrize("prefix,run", [(40000, 80000), (33000, 66000), (1000, 120000), (70000, 40000), (40000, 200000)])
+def test_emulated_long_match_crosses_sweep_intervals(prefix, run):
+    # found by a 110 s GPU soak in round 3 (seed 4002, case 16282): levels 10/30 accepted a candidate out of a slot whose "65536 old"
+    # stamp had wrapped to a young age behind a 70 000-byte match — the sweeps due inside the match are now made up at the match
+    data = _long_match_case(prefix, run, prefix + run)
+    for level in (10, 30, 11, 21, 22):
+        want = util.oracle_compress(data, level)
+        for seed in (1, 2):
+            assert emul_compress(data, level, seed) == want, (level, seed)

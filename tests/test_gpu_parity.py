@@ -64,6 +64,23 @@ def test_long_range_corpus(L):
             assert r == g["size"] and util.sha(out) == g["sha256"], (name, level)
 
 
+def test_long_match_crosses_sweep_intervals(L):
+    """Round-3 soak finding (tests/test_emulator.py::test_emulated_long_match_crosses_sweep_intervals): behind a match that moves ip
+    across several sweep intervals of the 17-bit LDS table, a slot stamped dead before the jump must still read as dead.  One block
+    per call and in a batch (every kind of wave), at every GPU level."""
+    from test_emulator import _long_match_case
+    from lizard_amd import api
+    cases = [_long_match_case(p, r, p + r) for p, r in ((40000, 80000), (33000, 66000), (1000, 120000), (70000, 40000), (40000, 200000))]
+    for level in gpu_levels(L):
+        for i, data in enumerate(cases):
+            out, r = gpu_compress(L, data, level)
+            assert out == util.oracle_compress(data, level), ("one block", level, i)
+    blob = b"".join(c[:131072].ljust(131072, b"\x55") for c in cases) * 8
+    for level in (10, 30, 11, 21):
+        for i, o in enumerate(api.compress_blocks(blob, 131072, level)):
+            assert o == util.oracle_compress(blob[i * 131072:(i + 1) * 131072], level), ("batch", level, i)
+
+
 def test_blocks_above_4mib(L):
     """Every size the reference takes (lib/lizard_compress.h:121) at the fast and priceFast levels: their tables keep positions
     modulo 2^17 / 2^22 / 2^24 and sweep.  A 17 MiB block crosses every one of those widths; the one-block path runs a single
