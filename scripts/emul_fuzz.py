@@ -2,7 +2,7 @@
 """CPU-side soak: the stitched random inputs of tests/test_random_parity.py through the SIMT emulator (the product's kernel bodies)
 against the oracle, every level, both table forms, until the time box is used up.  TEST INFRASTRUCTURE (uses tests/ and oracle/).
 
-    python scripts/emul_fuzz.py <seed> <seconds> [max_size] [long]
+    python scripts/emul_fuzz.py <seed> <seconds> [max_size] [long|default] [levels, comma-separated]
 
 `long`: inputs made of LONG segments instead (runs, periodic stretches and copies of 20 000 - 200 000 bytes between noise and
 generator data): single matches that cross sub-block-sized distances, the case the round-3 soak found a bug in.
@@ -51,11 +51,12 @@ def main():
     seed, box = int(sys.argv[1]), float(sys.argv[2])
     max_size = int(sys.argv[3]) if len(sys.argv) > 3 else 300000
     gen = make_long_case if len(sys.argv) > 4 and sys.argv[4] == "long" else make_case
+    levels = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else LEVELS
     rng = random.Random(seed)
     t0, n, bad = time.time(), 0, 0
     while time.time() - t0 < box:
         data = gen(rng, max_size)
-        level = rng.choice(LEVELS)
+        level = rng.choice(levels)
         eseed = rng.randrange(1, 9)
         if emul_compress(data, level, eseed) != util.oracle_compress(data, level):
             bad += 1
