@@ -1,11 +1,17 @@
 /*
  * lizard_amd.h — C ABI of liblizard_amd.so, the MI355X-native Lizard block-compress path.
  *
- * Part 1 is the reference's own block-compression ABI (same names, argument meaning and error
- * behaviour), so that a program written against inikep/lizard's lib/lizard_compress.h links against
- * this library unchanged.  Each entry cites the reference declaration it replaces.
- * Part 2 is the batch extension the GPU needs (the reference API is one-block-synchronous; see
- * SURVEY.md §8b): many independent blocks per call, host- or device-resident.
+ * The library is a link-time replacement of the reference's liblizard: it exports every symbol of
+ * lib/dll/liblizard.def, of lib/lizard_frame.h and the Lizard_XXH* hash functions the reference's programs use, with the
+ * reference's names, argument meaning and error behaviour — the sources under programs/, tests/fuzzer.c, tests/frametest.c and
+ * tests/fullbench.c link against it with no reference object at all (oracle/Makefile) — plus the LizardGPU_*
+ * extension.  Each entry cites the reference declaration it replaces.
+ *   Part 1   block compression      lib/lizard_compress.h       on the GPU, no host path
+ *   Part 1b  block decompression    lib/lizard_decompress.h     one block per call: on the calling thread (not the accelerated path)
+ *   Part 1c  frames                 lib/lizard_frame.h          compression batched on the GPU; decompression on the host
+ *   Part 1d  XXH32 / XXH64          lib/xxhash/xxhash.h         (XXH_NAMESPACE=Lizard_, lib/Makefile:52)
+ *   Part 2   batch extension (ours): many independent blocks per call, host- or device-resident, several GPUs, decompression
+ *   Part 3   the strict frame twins of rounds 2-3 (LizardGPU_compressFrame ...)
  *
  * Plain C, plain pointers and sizes; no HIP or torch types in any signature (a HIP stream is passed
  * as an opaque void*).
@@ -74,6 +80,107 @@ Lizard_stream_t* Lizard_createStream_MinLevel(void);
 int Lizard_loadDict(Lizard_stream_t* streamPtr, const char* dictionary, int dictSize);
 int Lizard_saveDict(Lizard_stream_t* streamPtr, char* safeBuffer, int dictSize);
 int Lizard_compress_continue(Lizard_stream_t* streamPtr, const char* src, char* dst, int srcSize, int maxDstSize);
+
+/* ======================= Part 1b: reference block decompression (lib/lizard_decompress.h) =======================
+ * One block per call, on the calling thread (lizard_amd/csrc/lizard_decode_host.c): the decoder is not the path this library
+ * accelerates, and one block is ~0.1 ms of host work against ~1 ms as a single wavefront.  Many independent blocks:
+ * LizardGPU_decompressBlocks_host / _device below.  Same results as the reference for every valid block; malformed input is
+ * refused (negative result) without reading outside source[0..compressedSize) or writing outside dest[0..maxDecompressedSize). */
+typedef struct Lizard_streamDecode_s Lizard_streamDecode_t;   /* 4 words, valid when zeroed (reference lib/lizard_common.h:195-200) */
+/* reference lib/lizard_decompress.h:64 / lib/lizard_decompress.c:267 */
+int Lizard_decompress_safe(const char* source, char* dest, int compressedSize, int maxDecompressedSize);
+/* reference lib/lizard_decompress.h:80 / lib/lizard_decompress.c:272: may stop once targetOutputSize bytes exist (returns >= that) */
+int Lizard_decompress_safe_partial(const char* source, char* dest, int compressedSize, int targetOutputSize, int maxDecompressedSize);
+/* reference lib/lizard_decompress.h:102-103,110 / lib/lizard_decompress.c:288-314 */
+Lizard_streamDecode_t* Lizard_createStreamDecode(void);
+int Lizard_freeStreamDecode(Lizard_streamDecode_t* Lizard_stream);
+int Lizard_setStreamDecode(Lizard_streamDecode_t* Lizard_streamDecode, const char* dictionary, int dictSize);
+/* reference lib/lizard_decompress.h:131 / lib/lizard_decompress.c:325: previous output is the history (prefix if contiguous) */
+int Lizard_decompress_safe_continue(Lizard_streamDecode_t* Lizard_streamDecode, const char* source, char* dest, int compressedSize, int maxDecompressedSize);
+/* reference lib/lizard_decompress.h:142 / lib/lizard_decompress.c:360, :374 */
+int Lizard_decompress_safe_usingDict(const char* source, char* dest, int compressedSize, int maxDecompressedSize, const char* dictStart, int dictSize);
+int Lizard_decompress_safe_forceExtDict(const char* source, char* dest, int compressedSize, int maxOutputSize, const char* dictStart, int dictSize);
+
+/* ======================= Part 1c: reference frame API (lib/lizard_frame.h) =======================
+ * Types as lib/lizard_frame.h:59-234 declares them (define LIZARD_AMD_NO_FRAME_TYPES before this header when the reference's
+ * lizard_frame.h is included too).  Compression: every run of blocks an Update / compressFrame call covers is ONE batch on the
+ * GPU (lizard_amd/csrc/lizard_frame_host.c).  Independent blocks: byte for byte the reference's frames (zero-state build).
+ * Linked blocks: valid frames whose blocks do not use their history (Lizard_compress_continue above).  A level without a GPU
+ * kernel or a GPU failure stores the blocks raw, as the reference's frame layer does when Lizard_compress_extState returns 0
+ * (lib/lizard_frame.c:456-469), after a line on stderr. */
+#ifndef LIZARD_AMD_NO_FRAME_TYPES
+typedef size_t LizardF_errorCode_t;
+typedef enum { LizardF_default = 0, LizardF_max128KB = 1, LizardF_max256KB = 2, LizardF_max1MB = 3, LizardF_max4MB = 4,
+               LizardF_max16MB = 5, LizardF_max64MB = 6, LizardF_max256MB = 7 } LizardF_blockSizeID_t;
+typedef enum { LizardF_blockLinked = 0, LizardF_blockIndependent } LizardF_blockMode_t;
+typedef enum { LizardF_noContentChecksum = 0, LizardF_contentChecksumEnabled } LizardF_contentChecksum_t;
+typedef enum { LizardF_frame = 0, LizardF_skippableFrame } LizardF_frameType_t;
+typedef struct {
+    LizardF_blockSizeID_t     blockSizeID;          /* 0 = default (128 KiB) */
+    LizardF_blockMode_t       blockMode;            /* 0 = linked (default), 1 = independent */
+    LizardF_contentChecksum_t contentChecksumFlag;
+    LizardF_frameType_t       frameType;
+    unsigned long long        contentSize;          /* != 0: the header carries the content size */
+    unsigned                  reserved[2];
+} LizardF_frameInfo_t;                              /* lib/lizard_frame.h:111-118 */
+typedef struct {
+    LizardF_frameInfo_t frameInfo;
+    int      compressionLevel;                      /* clamped like Lizard_createStream (lib/lizard_compress.c:303-308) */
+    unsigned autoFlush;                             /* 1 = every Update call ends on a block boundary (no buffering) */
+    unsigned reserved[4];
+} LizardF_preferences_t;                            /* lib/lizard_frame.h:120-125 */
+typedef struct LizardF_cctx_s* LizardF_compressionContext_t;      /* lib/lizard_frame.h:148 */
+typedef struct { unsigned stableSrc; unsigned reserved[3]; } LizardF_compressOptions_t;      /* :150-154 */
+typedef struct LizardF_dctx_s* LizardF_decompressionContext_t;    /* :229 */
+typedef struct { unsigned stableDst; unsigned reserved[3]; } LizardF_decompressOptions_t;    /* :231-234 */
+#define LIZARDF_VERSION 100
+#endif
+/* reference lib/lizard_frame.h:59-60 / lib/lizard_frame.c:179-189; codes are (size_t)-LizardF_ERROR_* (lib/lizard_frame_static.h:57-67) */
+unsigned    LizardF_isError(size_t code);
+const char* LizardF_getErrorName(size_t code);
+/* reference lib/lizard_frame.h:131,143 / lib/lizard_frame.c:229,260 */
+size_t LizardF_compressFrameBound(size_t srcSize, const LizardF_preferences_t* preferencesPtr);
+size_t LizardF_compressFrame(void* dstBuffer, size_t dstMaxSize, const void* srcBuffer, size_t srcSize, const LizardF_preferences_t* preferencesPtr);
+/* reference lib/lizard_frame.h:159-160,172,181,193,205,216 / lib/lizard_frame.c:329,346,362,432,501,610,651 */
+size_t LizardF_createCompressionContext(LizardF_compressionContext_t* cctxPtr, unsigned version);
+size_t LizardF_freeCompressionContext(LizardF_compressionContext_t cctx);
+size_t LizardF_compressBegin(LizardF_compressionContext_t cctx, void* dstBuffer, size_t dstMaxSize, const LizardF_preferences_t* prefsPtr);
+size_t LizardF_compressBound(size_t srcSize, const LizardF_preferences_t* prefsPtr);
+size_t LizardF_compressUpdate(LizardF_compressionContext_t cctx, void* dstBuffer, size_t dstMaxSize, const void* srcBuffer, size_t srcSize,
+                              const LizardF_compressOptions_t* cOptPtr);
+size_t LizardF_flush(LizardF_compressionContext_t cctx, void* dstBuffer, size_t dstMaxSize, const LizardF_compressOptions_t* cOptPtr);
+size_t LizardF_compressEnd(LizardF_compressionContext_t cctx, void* dstBuffer, size_t dstMaxSize, const LizardF_compressOptions_t* cOptPtr);
+/* reference lib/lizard_frame.h:247-248,265,297 / lib/lizard_frame.c:689,699,871,980.  Blocks are decoded by Part 1b's decoder;
+ * the context keeps the 16 MiB history of a linked frame itself (stableDst is accepted and not needed). */
+size_t LizardF_createDecompressionContext(LizardF_decompressionContext_t* dctxPtr, unsigned version);
+size_t LizardF_freeDecompressionContext(LizardF_decompressionContext_t dctx);
+size_t LizardF_getFrameInfo(LizardF_decompressionContext_t dctx, LizardF_frameInfo_t* frameInfoPtr, const void* srcBuffer, size_t* srcSizePtr);
+size_t LizardF_decompress(LizardF_decompressionContext_t dctx, void* dstBuffer, size_t* dstSizePtr, const void* srcBuffer, size_t* srcSizePtr,
+                          const LizardF_decompressOptions_t* dOptPtr);
+
+/* ======================= Part 1d: XXH32 / XXH64 (lib/xxhash/xxhash.h with XXH_NAMESPACE=Lizard_) =======================
+ * programs/bench.c, tests/fuzzer.c and tests/frametest.c call these; the state structs are the caller's (the reference's
+ * XXH32_state_t / XXH64_state_t: 48 / 88 bytes), this library's layouts fit inside them.  XXH_errorcode: 0 = ok. */
+struct Lizard_XXH32_state_s; struct Lizard_XXH64_state_s;
+unsigned Lizard_XXH_versionNumber(void);
+unsigned Lizard_XXH32(const void* input, size_t length, unsigned seed);                                   /* xxhash.h:167 */
+struct Lizard_XXH32_state_s* Lizard_XXH32_createState(void);                                             /* :171-177 */
+int      Lizard_XXH32_freeState(struct Lizard_XXH32_state_s* statePtr);
+void     Lizard_XXH32_copyState(struct Lizard_XXH32_state_s* dst, const struct Lizard_XXH32_state_s* src);
+int      Lizard_XXH32_reset(struct Lizard_XXH32_state_s* statePtr, unsigned seed);
+int      Lizard_XXH32_update(struct Lizard_XXH32_state_s* statePtr, const void* input, size_t length);
+unsigned Lizard_XXH32_digest(const struct Lizard_XXH32_state_s* statePtr);
+void     Lizard_XXH32_canonicalFromHash(unsigned char* dst, unsigned hash);                              /* :204-205 (big-endian bytes) */
+unsigned Lizard_XXH32_hashFromCanonical(const unsigned char* src);
+unsigned long long Lizard_XXH64(const void* input, size_t length, unsigned long long seed);              /* :225 */
+struct Lizard_XXH64_state_s* Lizard_XXH64_createState(void);                                             /* :229-235 */
+int      Lizard_XXH64_freeState(struct Lizard_XXH64_state_s* statePtr);
+void     Lizard_XXH64_copyState(struct Lizard_XXH64_state_s* dst, const struct Lizard_XXH64_state_s* src);
+int      Lizard_XXH64_reset(struct Lizard_XXH64_state_s* statePtr, unsigned long long seed);
+int      Lizard_XXH64_update(struct Lizard_XXH64_state_s* statePtr, const void* input, size_t length);
+unsigned long long Lizard_XXH64_digest(const struct Lizard_XXH64_state_s* statePtr);
+void     Lizard_XXH64_canonicalFromHash(unsigned char* dst, unsigned long long hash);                    /* :239-240 */
+unsigned long long Lizard_XXH64_hashFromCanonical(const unsigned char* src);
 
 /* ======================= Part 2: batch extension (ours) ======================= */
 
@@ -227,21 +334,8 @@ int LizardGPU_residentWaves(void);
  * linked-block frames larger than one block (blockMode_invalid), levels without a GPU kernel
  * (compressionLevel_invalid) and skippable frames (frameType_unknown).
  * ===================================================================================================== */
-typedef struct {
-    unsigned           blockSizeID;          /* LizardF_blockSizeID_t: 0 = default (128 KiB), 1..7 = 128K,256K,1M,4M,16M,64M,256M */
-    unsigned           blockMode;            /* LizardF_blockMode_t: 0 = linked, 1 = independent */
-    unsigned           contentChecksumFlag;  /* 0 / 1 */
-    unsigned           frameType;            /* 0 = frame */
-    unsigned long long contentSize;          /* != 0: the header carries the content size */
-    unsigned           reserved[2];
-} LizardGPU_frameInfo_t;                     /* == LizardF_frameInfo_t */
-
-typedef struct {
-    LizardGPU_frameInfo_t frameInfo;
-    int      compressionLevel;               /* clamped like Lizard_createStream (lib/lizard_compress.c:303-308) */
-    unsigned autoFlush;                      /* 1 = every Update call ends on a block boundary (no buffering) */
-    unsigned reserved[4];
-} LizardGPU_framePrefs_t;                    /* == LizardF_preferences_t */
+typedef LizardF_frameInfo_t   LizardGPU_frameInfo_t;
+typedef LizardF_preferences_t LizardGPU_framePrefs_t;
 
 enum {                                       /* LizardF_errorCodes, lib/lizard_frame_static.h:57-67 */
     LIZARDGPU_FRAME_ERR_GENERIC = 1, LIZARDGPU_FRAME_ERR_maxBlockSize_invalid = 2, LIZARDGPU_FRAME_ERR_blockMode_invalid = 3,
@@ -263,7 +357,7 @@ size_t LizardGPU_compressFrame(void* dstBuffer, size_t dstMaxSize, const void* s
  * LizardF_compressBegin (:169), LizardF_compressBound (:178), LizardF_compressUpdate (:190), LizardF_flush (:202) and
  * LizardF_compressEnd (:213).  The reference's LizardF_compressOptions_t only carries stableSrc, which matters to
  * linked blocks alone, so the argument is dropped. */
-typedef struct LizardGPU_cctx_s LizardGPU_cctx_t;
+typedef struct LizardF_cctx_s LizardGPU_cctx_t;      /* the object LizardF_createCompressionContext makes, in its strict mode */
 int    LizardGPU_createCompressionContext(LizardGPU_cctx_t** cctxPtr);
 int    LizardGPU_freeCompressionContext(LizardGPU_cctx_t* cctx);
 size_t LizardGPU_compressBegin(LizardGPU_cctx_t* cctx, void* dstBuffer, size_t dstMaxSize, const LizardGPU_framePrefs_t* preferencesPtr);

@@ -1,100 +1,78 @@
 /*
- * lizard_frame_host.c — `.liz` frame production on top of the batched GPU block path.
+ * lizard_frame_host.c — the reference's FRAME layer (lib/lizard_frame.h: LizardF_*) on top of the batched GPU block path
+ * (SURVEY.md section 8b "symbols a replacement must export", section 8f rank 2).
  *
- * A streaming twin of the reference's frame compressor — LizardGPU_compressBegin / _compressUpdate / _flush /
- * _compressEnd follow lib/lizard_frame.c:362-424, :501-599, :610-637, :651-677 call for call — and the one-shot
- * LizardGPU_compressFrame (lizard_frame.c:260-316) built on it exactly like the reference builds its own.  Output is
- * byte for byte what the reference writes for the same preferences and the same sequence of calls in
- * independent-block mode when it is built with -DLIZARD_RESET_MEM (the zero-state oracle of DESIGN.md §2).
+ * Compression.  LizardF_compressBegin / _compressUpdate / _flush / _compressEnd follow lib/lizard_frame.c:362-424, :501-599,
+ * :610-637, :651-677 call for call and LizardF_compressFrame (:260-316) is built on them like the reference builds its own:
+ * same header, same LE32 block records (bit 31 = stored raw), same end mark and XXH32 content checksum, for the same
+ * preferences and the same sequence of calls.  What is different is WHERE the work happens.  The reference compresses one block
+ * per Lizard_compress_extState call (:544-556); here every run of blocks an Update call covers — the full blocks it finds in the
+ * caller's buffer plus, with autoFlush, the ragged tail — is ONE batch: the blocks are compressed by the block kernels and the
+ * frame's block records are assembled ON THE DEVICE by a prefix sum + compaction (lz_pack.h), so that exactly the bytes of the
+ * frame body cross PCIe, once, through pinned staging (lzgpu_frame_records, lizard_pipeline_host.c).  The XXH32 content checksum
+ * is inherently sequential; it runs on a helper thread of the host while the GPU works.  A program written against
+ * lizard_frame.h — the reference's CLI (programs/lizardio.c), tests/frametest.c, tests/fullbench.c — reaches the batch path
+ * without a source change.
+ *   independent blocks : byte for byte what the reference writes when it is built with -DLIZARD_RESET_MEM.
+ *   linked blocks      : the reference's Lizard_compress_continue chain is serial by definition; this library's
+ *                        Lizard_compress_continue is history-free (include/lizard_amd.h), so a linked frame carries the linked
+ *                        flag and independently compressed blocks — valid, decodable by any Lizard frame decoder, same batch
+ *                        path; not the reference's linked-mode bytes.
+ *   a level without a GPU kernel, or no usable GPU: Lizard_compress_extState returns 0 there, and the reference's frame layer
+ *                        stores such blocks raw (:456-469).  Same here, after one loud line on stderr.
+ * The LizardGPU_* twins of round 2/3 remain as the STRICT form: they promise byte identity with the reference and therefore
+ * refuse linked frames above one block, levels without a kernel and GPU failures instead of storing raw.
  *
- * What is different is WHERE the work happens: the reference compresses one block per Lizard_compress_extState
- * call (:544-556); here every run of blocks an Update call covers — the full blocks it finds in the caller's buffer
- * plus, with autoFlush, the ragged tail — is ONE batch: the blocks are compressed by the block kernels, and the
- * frame's block records (LE32 size word, bit 31 = stored raw, payload; :456-469) are assembled ON THE DEVICE by a
- * prefix sum + compaction (lz_pack.h), so that exactly the bytes of the frame body cross PCIe, once, through pinned
- * staging (lzgpu_frame_records, lizard_gpu.hip).  The XXH32 content checksum is inherently sequential; it runs on a
- * helper thread of the host while the GPU works.
- *
- * The symbols carry the LizardGPU_ prefix on purpose: lib/lizard_frame.c holds frame compression and decompression
- * in one object, so a program keeps linking the reference's LizardF_* (decoder included) and calls these where it
- * wants GPU-rate frames.  Linked-block frames are a serial dependency chain between blocks:
- * they are refused here (blockMode_invalid), never emulated.  XXH32 (lib/xxhash/xxhash.c, public algorithm) is
- * restated below.
+ * Decompression.  LizardF_decompress / _getFrameInfo (lib/lizard_frame.c:743-1362) as a state machine of its own: header,
+ * block header, raw block, compressed block, flush, suffix, skippable frames; any segmentation of input and output.  Blocks
+ * are decoded by this library's host decoder (lizard_decode_host.c) — the decoder is not the path this library accelerates —
+ * straight into the caller's buffer when a whole block fits there, otherwise through an internal buffer that, for linked
+ * frames, also holds the 16 MiB of history the next block may refer to (the caller's buffer is never relied on as history).
  */
 #include "../../include/lizard_amd.h"
 #include "lizard_gpu_shim.h"
+#include "lizard_xxhash.h"
 
 #include <pthread.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #define LZF_MAGIC            0x184D2206u          /* lizard_frame.c:118 */
+#define LZF_MAGIC_SKIPPABLE  0x184D2A50u          /* :117 */
+#define LZF_MIN_HEADER       7u                   /* minFHSize, :122 */
 #define LZF_MAX_HEADER       15u                  /* maxFHSize, :123 */
-#define LZF_ERR(code)        ((size_t)-(long)(LIZARDGPU_FRAME_ERR_##code))
+#define LZF_DICT             ((size_t)1 << 24)    /* LIZARD_DICT_SIZE */
+#define LZF_ERR(code)        ((size_t)-(long)(LizardF_ERROR_##code))
 
-/* ---- XXH32 (xxhash specification), streaming form ---- */
-#define XP1 2654435761u
-#define XP2 2246822519u
-#define XP3 3266489917u
-#define XP4 668265263u
-#define XP5 374761393u
-typedef struct { uint32_t v[4]; uint8_t buf[16]; uint32_t fill; uint64_t total; uint32_t seed; } xxh32_t;
-static uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+/* LizardF_errorCodes, lib/lizard_frame_static.h:57-67 */
+enum {
+    LizardF_OK_NoError = 0, LizardF_ERROR_GENERIC, LizardF_ERROR_maxBlockSize_invalid, LizardF_ERROR_blockMode_invalid,
+    LizardF_ERROR_contentChecksumFlag_invalid, LizardF_ERROR_compressionLevel_invalid, LizardF_ERROR_headerVersion_wrong,
+    LizardF_ERROR_blockChecksum_unsupported, LizardF_ERROR_reservedFlag_set, LizardF_ERROR_allocation_failed,
+    LizardF_ERROR_srcSize_tooLarge, LizardF_ERROR_dstMaxSize_tooSmall, LizardF_ERROR_frameHeader_incomplete,
+    LizardF_ERROR_frameType_unknown, LizardF_ERROR_frameSize_wrong, LizardF_ERROR_srcPtr_wrong, LizardF_ERROR_decompressionFailed,
+    LizardF_ERROR_headerChecksum_invalid, LizardF_ERROR_contentChecksum_invalid, LizardF_ERROR_maxCode
+};
+static const char* const kErrorNames[] = {
+    "OK_NoError", "ERROR_GENERIC", "ERROR_maxBlockSize_invalid", "ERROR_blockMode_invalid", "ERROR_contentChecksumFlag_invalid",
+    "ERROR_compressionLevel_invalid", "ERROR_headerVersion_wrong", "ERROR_blockChecksum_unsupported", "ERROR_reservedFlag_set",
+    "ERROR_allocation_failed", "ERROR_srcSize_tooLarge", "ERROR_dstMaxSize_tooSmall", "ERROR_frameHeader_incomplete",
+    "ERROR_frameType_unknown", "ERROR_frameSize_wrong", "ERROR_srcPtr_wrong", "ERROR_decompressionFailed",
+    "ERROR_headerChecksum_invalid", "ERROR_contentChecksum_invalid", "ERROR_maxCode"
+};
+
+unsigned LizardF_isError(size_t code) { return code > (size_t)-(long)LizardF_ERROR_maxCode; }          /* lizard_frame.c:179-182 */
+const char* LizardF_getErrorName(size_t code)                                                          /* :184-189 */
+{
+    return LizardF_isError(code) ? kErrorNames[(size_t)0 - code] : "Unspecified error code";
+}
+
 static uint32_t rd32le(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
-static uint32_t xround(uint32_t acc, uint32_t in) { return rotl32(acc + in * XP2, 13) * XP1; }
-static void xxh32_reset(xxh32_t* s, uint32_t seed)
-{
-    s->v[0] = seed + XP1 + XP2; s->v[1] = seed + XP2; s->v[2] = seed; s->v[3] = seed - XP1;
-    s->fill = 0; s->total = 0; s->seed = seed;
-}
-static void xxh32_update(xxh32_t* s, const void* data, size_t len)
-{
-    const uint8_t* p = (const uint8_t*)data;
-    s->total += len;
-    if (s->fill) {
-        const size_t take = 16 - s->fill < len ? 16 - s->fill : len;
-        memcpy(s->buf + s->fill, p, take);
-        s->fill += (uint32_t)take; p += take; len -= take;
-        if (s->fill < 16) return;
-        s->v[0] = xround(s->v[0], rd32le(s->buf)); s->v[1] = xround(s->v[1], rd32le(s->buf + 4));
-        s->v[2] = xround(s->v[2], rd32le(s->buf + 8)); s->v[3] = xround(s->v[3], rd32le(s->buf + 12));
-        s->fill = 0;
-    }
-    {
-        uint32_t v1 = s->v[0], v2 = s->v[1], v3 = s->v[2], v4 = s->v[3];
-        while (len >= 16) {
-            v1 = xround(v1, rd32le(p)); v2 = xround(v2, rd32le(p + 4));
-            v3 = xround(v3, rd32le(p + 8)); v4 = xround(v4, rd32le(p + 12));
-            p += 16; len -= 16;
-        }
-        s->v[0] = v1; s->v[1] = v2; s->v[2] = v3; s->v[3] = v4;
-    }
-    if (len) { memcpy(s->buf, p, len); s->fill = (uint32_t)len; }
-}
-static uint32_t xxh32_digest(const xxh32_t* s)
-{
-    const uint8_t* p = s->buf;
-    const uint8_t* const end = p + s->fill;
-    uint32_t h = s->total >= 16 ? rotl32(s->v[0], 1) + rotl32(s->v[1], 7) + rotl32(s->v[2], 12) + rotl32(s->v[3], 18)
-                                : s->seed + XP5;
-    h += (uint32_t)s->total;
-    while (p + 4 <= end) { h = rotl32(h + rd32le(p) * XP3, 17) * XP4; p += 4; }
-    while (p < end) { h = rotl32(h + (uint32_t)*p * XP5, 11) * XP1; p++; }
-    h ^= h >> 15; h *= XP2; h ^= h >> 13; h *= XP3; h ^= h >> 16;
-    return h;
-}
-static uint32_t xxh32(const void* data, size_t len, uint32_t seed)
-{
-    xxh32_t s;
-    xxh32_reset(&s, seed);
-    xxh32_update(&s, data, len);
-    return xxh32_digest(&s);
-}
-
 static void wr32le(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
 
-/* LizardF_getBlockSize, lizard_frame.c:192-201 (0 = default = 128 KiB) */
+/* LizardF_getBlockSize, lizard_frame.c:192-201 (0 = default = 128 KiB); 0 = invalid id */
 static size_t block_size_of(unsigned id)
 {
     static const size_t sizes[7] = { (size_t)128 << 10, (size_t)256 << 10, (size_t)1 << 20, (size_t)4 << 20,
@@ -121,44 +99,50 @@ static int clamp_level(int level)                                /* Lizard_creat
     return level;
 }
 
-unsigned LizardGPU_frameIsError(size_t code) { return code > (size_t)-(long)LIZARDGPU_FRAME_ERR_maxCode; }   /* :179-182 */
+/* ================================================= compression ================================================= */
 
-/* ---- streaming context (twin of LizardF_cctx_t, lizard_frame.c:96-113) ---- */
-struct LizardGPU_cctx_s {
-    LizardGPU_framePrefs_t prefs;
+/* twin of LizardF_cctx_t, lizard_frame.c:96-113 (the block compressor's state lives on the device) */
+struct LizardF_cctx_s {
+    LizardF_preferences_t prefs;
+    unsigned version;
     unsigned stage;                  /* 0 = expects Begin, 1 = header written */
+    unsigned strict;                 /* the LizardGPU_* twins: refuse what cannot be byte-identical instead of degrading */
     size_t   blockSize;
     int      level;
     uint8_t* tmpIn;  size_t tmpInSize, tmpCap;
     unsigned long long totalIn;
-    xxh32_t  xxh;
+    Lizard_XXH32_state_t xxh;
 };
 
-int LizardGPU_createCompressionContext(LizardGPU_cctx_t** cctxPtr)
+size_t LizardF_createCompressionContext(LizardF_compressionContext_t* cctxPtr, unsigned version)      /* :329-343 */
 {
-    if (!cctxPtr) return -(int)LIZARDGPU_FRAME_ERR_GENERIC;
-    *cctxPtr = (LizardGPU_cctx_t*)calloc(1, sizeof(LizardGPU_cctx_t));
-    return *cctxPtr ? 0 : -(int)LIZARDGPU_FRAME_ERR_allocation_failed;
+    LizardF_compressionContext_t c;
+    if (!cctxPtr) return LZF_ERR(GENERIC);
+    c = (LizardF_compressionContext_t)calloc(1, sizeof(struct LizardF_cctx_s));
+    if (!c) return LZF_ERR(allocation_failed);
+    c->version = version;
+    *cctxPtr = c;
+    return LizardF_OK_NoError;
 }
 
-int LizardGPU_freeCompressionContext(LizardGPU_cctx_t* cctx)
+size_t LizardF_freeCompressionContext(LizardF_compressionContext_t c)                                   /* :346-357 */
 {
-    if (cctx) { free(cctx->tmpIn); free(cctx); }
-    return 0;
+    if (c) { free(c->tmpIn); free(c); }
+    return LizardF_OK_NoError;
 }
 
 /* LizardF_compressBound, lizard_frame.c:432-451 (same value) */
-size_t LizardGPU_compressBound(size_t srcSize, const LizardGPU_framePrefs_t* prefsPtr)
+size_t LizardF_compressBound(size_t srcSize, const LizardF_preferences_t* prefsPtr)
 {
-    LizardGPU_framePrefs_t worst;
+    LizardF_preferences_t worst;
     memset(&worst, 0, sizeof worst);
     worst.frameInfo.contentChecksumFlag = 1;
     {
-        const LizardGPU_framePrefs_t* p = prefsPtr ? prefsPtr : &worst;
+        const LizardF_preferences_t* p = prefsPtr ? prefsPtr : &worst;
         const size_t blockSize = block_size_of(p->frameInfo.blockSizeID);
         if (!blockSize) return LZF_ERR(maxBlockSize_invalid);
         {
-            const size_t nbBlocks = srcSize / blockSize + 1;
+            const size_t nbBlocks = (unsigned)(srcSize / blockSize) + 1;
             const size_t last = p->autoFlush ? srcSize % blockSize : blockSize;
             return 4 * nbBlocks + blockSize * (nbBlocks - 1) + last + 4 + (size_t)p->frameInfo.contentChecksumFlag * 4;
         }
@@ -166,7 +150,7 @@ size_t LizardGPU_compressBound(size_t srcSize, const LizardGPU_framePrefs_t* pre
 }
 
 /* LizardF_compressBegin, lizard_frame.c:362-424 */
-size_t LizardGPU_compressBegin(LizardGPU_cctx_t* c, void* dstBuffer, size_t dstMaxSize, const LizardGPU_framePrefs_t* prefsPtr)
+size_t LizardF_compressBegin(LizardF_compressionContext_t c, void* dstBuffer, size_t dstMaxSize, const LizardF_preferences_t* prefsPtr)
 {
     uint8_t* dst = (uint8_t*)dstBuffer;
     if (!c || !dst) return LZF_ERR(GENERIC);
@@ -176,11 +160,12 @@ size_t LizardGPU_compressBegin(LizardGPU_cctx_t* c, void* dstBuffer, size_t dstM
     if (c->prefs.frameInfo.blockSizeID == 0) c->prefs.frameInfo.blockSizeID = 1;                      /* :385 */
     c->blockSize = block_size_of(c->prefs.frameInfo.blockSizeID);
     if (!c->blockSize) return LZF_ERR(maxBlockSize_invalid);
-    if (c->prefs.frameInfo.frameType != 0) return LZF_ERR(frameType_unknown);
-    if (c->prefs.frameInfo.blockMode != 1) return LZF_ERR(blockMode_invalid);                        /* linked: not on the GPU path */
     c->level = clamp_level(c->prefs.compressionLevel);
-    if (!LizardGPU_levelSupported(c->level)) return LZF_ERR(compressionLevel_invalid);
-    if (c->blockSize > LizardGPU_maxBlockSize(c->level)) return LZF_ERR(maxBlockSize_invalid);       /* per-level limit of the kernels */
+    if (c->strict) {
+        if (c->prefs.frameInfo.frameType != 0) return LZF_ERR(frameType_unknown);
+        if (c->prefs.frameInfo.blockMode != 1) return LZF_ERR(blockMode_invalid);                    /* linked: not byte-identical */
+        if (!LizardGPU_levelSupported(c->level)) return LZF_ERR(compressionLevel_invalid);
+    }
     if (!c->prefs.autoFlush && c->tmpCap < c->blockSize) {                                           /* :389-399 */
         free(c->tmpIn);
         c->tmpIn = (uint8_t*)malloc(c->blockSize);
@@ -188,7 +173,7 @@ size_t LizardGPU_compressBegin(LizardGPU_cctx_t* c, void* dstBuffer, size_t dstM
         if (!c->tmpIn) return LZF_ERR(allocation_failed);
     }
     c->tmpInSize = 0; c->totalIn = 0;
-    xxh32_reset(&c->xxh, 0);
+    Lizard_XXH32_reset(&c->xxh, 0);
     wr32le(dst, LZF_MAGIC); dst += 4;                                                                /* :403-424 */
     {
         uint8_t* const headerStart = dst;
@@ -199,18 +184,45 @@ size_t LizardGPU_compressBegin(LizardGPU_cctx_t* c, void* dstBuffer, size_t dstM
             wr32le(dst, (uint32_t)c->prefs.frameInfo.contentSize); wr32le(dst + 4, (uint32_t)(c->prefs.frameInfo.contentSize >> 32));
             dst += 8;
         }
-        *dst = (uint8_t)(xxh32(headerStart, (size_t)(dst - headerStart), 0) >> 8);                   /* :219-223 */
+        *dst = (uint8_t)(Lizard_XXH32(headerStart, (size_t)(dst - headerStart), 0) >> 8);            /* :219-223 */
         dst++;
     }
     c->stage = 1;
     return (size_t)(dst - (uint8_t*)dstBuffer);
 }
 
-struct crc_job { xxh32_t* st; const void* data; size_t len; };
-static void* crc_thread(void* arg) { struct crc_job* j = (struct crc_job*)arg; xxh32_update(j->st, j->data, j->len); return NULL; }
+/* The block records of nb blocks (blockSize each, the last one `last` bytes) at src, packed into dst: one batch on the GPU.
+ * Non-strict contexts degrade like the reference's frame layer does when Lizard_compress_extState returns 0 (:456-469): every
+ * block of the batch is stored raw, after one line on stderr. */
+static int frame_records(LizardF_compressionContext_t c, const uint8_t* src, size_t nb, size_t blockSize, size_t last,
+                         uint8_t* dst, size_t cap, size_t* written)
+{
+    static int warned = 0;
+    size_t i, need;
+    if (LizardGPU_levelSupported(c->level) && lzgpu_frame_records(src, nb, blockSize, last, dst, cap, written, c->level) == 0) return 0;
+    if (c->strict) return -1;
+    if (!__atomic_exchange_n(&warned, 1, __ATOMIC_RELAXED))
+        fprintf(stderr, "liblizard_amd: frame blocks at level %d are stored uncompressed: %s (no CPU fallback in this library)\n", c->level,
+                LizardGPU_levelSupported(c->level) ? LizardGPU_lastError() : "level not implemented on the GPU path");
+    need = (nb - 1) * (blockSize + 4) + last + 4;
+    if (need > cap) return -1;
+    for (i = 0; i < nb; i++) {
+        const size_t n = i + 1 == nb ? last : blockSize;
+        wr32le(dst, (uint32_t)n | 0x80000000u);
+        memcpy(dst + 4, src + i * blockSize, n);
+        dst += 4 + n;
+    }
+    *written = need;
+    return 0;
+}
 
-/* LizardF_compressUpdate, lizard_frame.c:501-599, independent blocks */
-size_t LizardGPU_compressUpdate(LizardGPU_cctx_t* c, void* dstBuffer, size_t dstMaxSize, const void* srcBuffer, size_t srcSize)
+struct crc_job { Lizard_XXH32_state_t* st; const void* data; size_t len; };
+static void* crc_thread(void* arg) { struct crc_job* j = (struct crc_job*)arg; Lizard_XXH32_update(j->st, j->data, j->len); return NULL; }
+
+/* LizardF_compressUpdate, lizard_frame.c:501-599.  compressOptionsPtr only carries stableSrc, which tells the reference whether
+ * it must save the dictionary of a linked stream (:563-571): there is no dictionary here. */
+size_t LizardF_compressUpdate(LizardF_compressionContext_t c, void* dstBuffer, size_t dstMaxSize, const void* srcBuffer, size_t srcSize,
+                              const LizardF_compressOptions_t* compressOptionsPtr)
 {
     const uint8_t* src = (const uint8_t*)srcBuffer;
     const uint8_t* const srcEnd = src + srcSize;
@@ -220,12 +232,13 @@ size_t LizardGPU_compressUpdate(LizardGPU_cctx_t* c, void* dstBuffer, size_t dst
     struct crc_job job;
     int threaded = 0;
     size_t result = 0;
+    (void)compressOptionsPtr;
     if (!c || c->stage != 1) return LZF_ERR(GENERIC);
-    if (dstMaxSize < LizardGPU_compressBound(srcSize, &c->prefs)) return LZF_ERR(dstMaxSize_tooSmall);
+    if (dstMaxSize < LizardF_compressBound(srcSize, &c->prefs)) return LZF_ERR(dstMaxSize_tooSmall);
     if (c->prefs.frameInfo.contentChecksumFlag == 1 && srcSize) {                                    /* :593-594, beside the GPU work */
         job.st = &c->xxh; job.data = srcBuffer; job.len = srcSize;
         if (srcSize >= ((size_t)1 << 20) && pthread_create(&th, NULL, crc_thread, &job) == 0) threaded = 1;
-        else xxh32_update(&c->xxh, srcBuffer, srcSize);
+        else Lizard_XXH32_update(&c->xxh, srcBuffer, srcSize);
     }
     do {
         size_t w = 0;
@@ -237,7 +250,7 @@ size_t LizardGPU_compressUpdate(LizardGPU_cctx_t* c, void* dstBuffer, size_t dst
             } else {
                 memcpy(c->tmpIn + c->tmpInSize, src, need);
                 src += need;
-                if (lzgpu_frame_records(c->tmpIn, 1, c->blockSize, c->blockSize, dst, (size_t)(dstEnd - dst), &w, c->level)) { result = LZF_ERR(GENERIC); break; }
+                if (frame_records(c, c->tmpIn, 1, c->blockSize, c->blockSize, dst, (size_t)(dstEnd - dst), &w)) { result = LZF_ERR(GENERIC); break; }
                 dst += w;
                 c->tmpInSize = 0;
             }
@@ -248,7 +261,7 @@ size_t LizardGPU_compressUpdate(LizardGPU_cctx_t* c, void* dstBuffer, size_t dst
             const size_t nb = full + ((c->prefs.autoFlush && tail) ? 1 : 0);
             if (nb) {
                 const size_t last = (c->prefs.autoFlush && tail) ? tail : c->blockSize;
-                if (lzgpu_frame_records(src, nb, c->blockSize, last, dst, (size_t)(dstEnd - dst), &w, c->level)) { result = LZF_ERR(GENERIC); break; }
+                if (frame_records(c, src, nb, c->blockSize, last, dst, (size_t)(dstEnd - dst), &w)) { result = LZF_ERR(GENERIC); break; }
                 dst += w;
                 src += (nb - 1) * c->blockSize + last;
             }
@@ -265,71 +278,411 @@ size_t LizardGPU_compressUpdate(LizardGPU_cctx_t* c, void* dstBuffer, size_t dst
 }
 
 /* LizardF_flush, lizard_frame.c:610-637 */
-size_t LizardGPU_flush(LizardGPU_cctx_t* c, void* dstBuffer, size_t dstMaxSize)
+size_t LizardF_flush(LizardF_compressionContext_t c, void* dstBuffer, size_t dstMaxSize, const LizardF_compressOptions_t* compressOptionsPtr)
 {
     size_t w = 0;
+    (void)compressOptionsPtr;
     if (!c) return LZF_ERR(GENERIC);
     if (c->tmpInSize == 0) return 0;
     if (c->stage != 1) return LZF_ERR(GENERIC);
     if (dstMaxSize < c->tmpInSize + 8) return LZF_ERR(dstMaxSize_tooSmall);
-    if (lzgpu_frame_records(c->tmpIn, 1, c->tmpInSize, c->tmpInSize, dstBuffer, dstMaxSize, &w, c->level)) return LZF_ERR(GENERIC);
+    if (frame_records(c, c->tmpIn, 1, c->tmpInSize, c->tmpInSize, (uint8_t*)dstBuffer, dstMaxSize, &w)) return LZF_ERR(GENERIC);
     c->tmpInSize = 0;
     return w;
 }
 
 /* LizardF_compressEnd, lizard_frame.c:651-677 */
-size_t LizardGPU_compressEnd(LizardGPU_cctx_t* c, void* dstBuffer, size_t dstMaxSize)
+size_t LizardF_compressEnd(LizardF_compressionContext_t c, void* dstBuffer, size_t dstMaxSize, const LizardF_compressOptions_t* compressOptionsPtr)
 {
     uint8_t* dst = (uint8_t*)dstBuffer;
-    const size_t f = LizardGPU_flush(c, dstBuffer, dstMaxSize);
-    if (LizardGPU_frameIsError(f)) return f;
+    const size_t f = LizardF_flush(c, dstBuffer, dstMaxSize, compressOptionsPtr);
+    if (LizardF_isError(f)) return f;
     dst += f;
     if (dstMaxSize - f < 4 + (size_t)c->prefs.frameInfo.contentChecksumFlag * 4) return LZF_ERR(dstMaxSize_tooSmall);
     wr32le(dst, 0); dst += 4;
-    if (c->prefs.frameInfo.contentChecksumFlag == 1) { wr32le(dst, xxh32_digest(&c->xxh)); dst += 4; }
+    if (c->prefs.frameInfo.contentChecksumFlag == 1) { wr32le(dst, Lizard_XXH32_digest(&c->xxh)); dst += 4; }
     c->stage = 0;
     if (c->prefs.frameInfo.contentSize && c->prefs.frameInfo.contentSize != c->totalIn) return LZF_ERR(frameSize_wrong);
     return (size_t)(dst - (uint8_t*)dstBuffer);
 }
 
 /* LizardF_compressFrameBound, lizard_frame.c:229-248 */
-size_t LizardGPU_compressFrameBound(size_t srcSize, const LizardGPU_framePrefs_t* prefsPtr)
+size_t LizardF_compressFrameBound(size_t srcSize, const LizardF_preferences_t* prefsPtr)
 {
-    LizardGPU_framePrefs_t prefs;
+    LizardF_preferences_t prefs;
     if (prefsPtr) prefs = *prefsPtr; else memset(&prefs, 0, sizeof prefs);
     prefs.frameInfo.blockSizeID = optimal_bsid(prefs.frameInfo.blockSizeID, srcSize);
     prefs.autoFlush = 1;
     {
-        const size_t b = LizardGPU_compressBound(srcSize, &prefs);
-        return LizardGPU_frameIsError(b) ? b : LZF_MAX_HEADER + b;
+        const size_t b = LizardF_compressBound(srcSize, &prefs);
+        return LizardF_isError(b) ? b : LZF_MAX_HEADER + b;
     }
 }
 
-/* LizardF_compressFrame, lizard_frame.c:260-316 */
-size_t LizardGPU_compressFrame(void* dstBuffer, size_t dstMaxSize, const void* srcBuffer, size_t srcSize,
-                               const LizardGPU_framePrefs_t* prefsPtr)
+static size_t compress_frame(void* dstBuffer, size_t dstMaxSize, const void* srcBuffer, size_t srcSize,
+                             const LizardF_preferences_t* prefsPtr, unsigned strict)
 {
-    LizardGPU_cctx_t c;
-    LizardGPU_framePrefs_t prefs;
+    struct LizardF_cctx_s c;
+    LizardF_preferences_t prefs;
     uint8_t* const dstStart = (uint8_t*)dstBuffer;
     uint8_t* dst = dstStart;
     size_t r;
     memset(&c, 0, sizeof c);
+    c.strict = strict;
     if (prefsPtr) prefs = *prefsPtr; else memset(&prefs, 0, sizeof prefs);
     if (prefs.frameInfo.contentSize != 0) prefs.frameInfo.contentSize = (unsigned long long)srcSize;      /* :279-280 */
     prefs.frameInfo.blockSizeID = optimal_bsid(prefs.frameInfo.blockSizeID, srcSize);                       /* :282 */
     prefs.autoFlush = 1;
     if (!block_size_of(prefs.frameInfo.blockSizeID)) return LZF_ERR(maxBlockSize_invalid);
     if (srcSize <= block_size_of(prefs.frameInfo.blockSizeID)) prefs.frameInfo.blockMode = 1;               /* :284-285 */
-    if (dstMaxSize < LizardGPU_compressFrameBound(srcSize, &prefs)) return LZF_ERR(dstMaxSize_tooSmall);   /* :289 */
-    r = LizardGPU_compressBegin(&c, dst, dstMaxSize, &prefs);
-    if (LizardGPU_frameIsError(r)) return r;
+    if (dstMaxSize < LizardF_compressFrameBound(srcSize, &prefs)) return LZF_ERR(dstMaxSize_tooSmall);     /* :289 */
+    r = LizardF_compressBegin(&c, dst, dstMaxSize, &prefs);
+    if (LizardF_isError(r)) return r;
     dst += r;
-    r = LizardGPU_compressUpdate(&c, dst, dstMaxSize - (size_t)(dst - dstStart), srcBuffer, srcSize);
-    if (LizardGPU_frameIsError(r)) return r;
+    r = LizardF_compressUpdate(&c, dst, dstMaxSize - (size_t)(dst - dstStart), srcBuffer, srcSize, NULL);
+    if (LizardF_isError(r)) return r;
     dst += r;
-    r = LizardGPU_compressEnd(&c, dst, dstMaxSize - (size_t)(dst - dstStart));
-    if (LizardGPU_frameIsError(r)) return r;
+    r = LizardF_compressEnd(&c, dst, dstMaxSize - (size_t)(dst - dstStart), NULL);
+    if (LizardF_isError(r)) return r;
     dst += r;
     return (size_t)(dst - dstStart);
+}
+
+/* LizardF_compressFrame, lizard_frame.c:260-316 */
+size_t LizardF_compressFrame(void* dstBuffer, size_t dstMaxSize, const void* srcBuffer, size_t srcSize, const LizardF_preferences_t* prefsPtr)
+{
+    return compress_frame(dstBuffer, dstMaxSize, srcBuffer, srcSize, prefsPtr, 0);
+}
+
+/* ---- the strict twins (include/lizard_amd.h part 3): LizardGPU_framePrefs_t == LizardF_preferences_t ---- */
+unsigned LizardGPU_frameIsError(size_t code) { return LizardF_isError(code); }
+size_t LizardGPU_compressFrameBound(size_t srcSize, const LizardGPU_framePrefs_t* p) { return LizardF_compressFrameBound(srcSize, p); }
+size_t LizardGPU_compressBound(size_t srcSize, const LizardGPU_framePrefs_t* p) { return LizardF_compressBound(srcSize, p); }
+size_t LizardGPU_compressFrame(void* dst, size_t cap, const void* src, size_t n, const LizardGPU_framePrefs_t* p) { return compress_frame(dst, cap, src, n, p, 1); }
+int LizardGPU_createCompressionContext(LizardGPU_cctx_t** cctxPtr)
+{
+    const size_t r = LizardF_createCompressionContext(cctxPtr, LIZARDF_VERSION);
+    if (LizardF_isError(r)) return -(int)((size_t)0 - r);
+    (*cctxPtr)->strict = 1;
+    return 0;
+}
+int    LizardGPU_freeCompressionContext(LizardGPU_cctx_t* c) { LizardF_freeCompressionContext(c); return 0; }
+size_t LizardGPU_compressBegin(LizardGPU_cctx_t* c, void* dst, size_t cap, const LizardGPU_framePrefs_t* p) { return LizardF_compressBegin(c, dst, cap, p); }
+size_t LizardGPU_compressUpdate(LizardGPU_cctx_t* c, void* dst, size_t cap, const void* src, size_t n) { return LizardF_compressUpdate(c, dst, cap, src, n, NULL); }
+size_t LizardGPU_flush(LizardGPU_cctx_t* c, void* dst, size_t cap) { return LizardF_flush(c, dst, cap, NULL); }
+size_t LizardGPU_compressEnd(LizardGPU_cctx_t* c, void* dst, size_t cap) { return LizardF_compressEnd(c, dst, cap, NULL); }
+
+/* ================================================= decompression ================================================= */
+
+enum { DS_HEADER = 0, DS_BLOCK_HEADER, DS_RAW, DS_BLOCK, DS_FLUSH, DS_SUFFIX, DS_SKIP };
+
+/* twin of LizardF_dctx_t, lizard_frame.c:115-135 */
+struct LizardF_dctx_s {
+    LizardF_frameInfo_t info;
+    unsigned version;
+    unsigned stage;                              /* DS_*; 0 = between frames (the value LizardF_freeDecompressionContext reports) */
+    int      infoValid;                          /* a frame header has been decoded since the last frame ended */
+    unsigned long long remaining;                /* content size still expected (headers that carry one) */
+    size_t   maxBlockSize;
+    const uint8_t* srcExpect;
+    uint8_t  small[16];  size_t smallFill, smallTarget;      /* frame header / block header / suffix being collected */
+    uint8_t* in;   size_t inCap, inFill, inTarget;           /* a compressed block that arrives in pieces */
+    uint8_t* hist; size_t histCap, histFill;                 /* decoded bytes: history of a linked frame, or one block waiting for room in dst */
+    size_t   outStart, outEnd;                               /* hist[outStart..outEnd) still has to reach the caller */
+    size_t   left;                                           /* bytes left of a raw block / a skippable frame */
+    Lizard_XXH32_state_t xxh;
+};
+
+size_t LizardF_createDecompressionContext(LizardF_decompressionContext_t* dctxPtr, unsigned version)  /* :689-697 */
+{
+    LizardF_decompressionContext_t d;
+    if (!dctxPtr) return LZF_ERR(GENERIC);
+    d = (LizardF_decompressionContext_t)calloc(1, sizeof(struct LizardF_dctx_s));
+    if (!d) return LZF_ERR(GENERIC);
+    d->version = version;
+    *dctxPtr = d;
+    return LizardF_OK_NoError;
+}
+
+size_t LizardF_freeDecompressionContext(LizardF_decompressionContext_t d)                              /* :699-710: 0 iff no frame is under way */
+{
+    size_t result = LizardF_OK_NoError;
+    if (d) { result = d->stage; free(d->in); free(d->hist); free(d); }
+    return result;
+}
+
+/* Header of a frame at p[0..n), n = 7 or 15 as its FLG byte says (LizardF_decodeHeader, :756-857).  0 or an error code. */
+static size_t decode_header(LizardF_decompressionContext_t d, const uint8_t* p, size_t n)
+{
+    const unsigned flg = p[4], bd = p[5];
+    const unsigned version = (flg >> 6) & 3u, blockMode = (flg >> 5) & 1u, blockChecksum = (flg >> 4) & 1u, contentSizeFlag = (flg >> 3) & 1u,
+                   contentChecksum = (flg >> 2) & 1u, bsid = (bd >> 4) & 7u;
+    size_t need;
+    if (version != 1) return LZF_ERR(headerVersion_wrong);                                           /* :811-816 */
+    if (blockChecksum) return LZF_ERR(blockChecksum_unsupported);
+    if (flg & 3u) return LZF_ERR(reservedFlag_set);
+    if (bd & 0x80u) return LZF_ERR(reservedFlag_set);
+    if (bsid < 1) return LZF_ERR(maxBlockSize_invalid);
+    if (bd & 0x0Fu) return LZF_ERR(reservedFlag_set);
+    if ((uint8_t)(Lizard_XXH32(p + 4, n - 5, 0) >> 8) != p[n - 1]) return LZF_ERR(headerChecksum_invalid);   /* :819-820 */
+    memset(&d->info, 0, sizeof d->info);
+    d->info.blockMode = (LizardF_blockMode_t)blockMode;
+    d->info.contentChecksumFlag = (LizardF_contentChecksum_t)contentChecksum;
+    d->info.blockSizeID = (LizardF_blockSizeID_t)bsid;
+    d->maxBlockSize = block_size_of(bsid);
+    d->remaining = 0;
+    if (contentSizeFlag) {
+        d->info.contentSize = (unsigned long long)rd32le(p + 6) | ((unsigned long long)rd32le(p + 10) << 32);
+        d->remaining = d->info.contentSize;
+    }
+    if (contentChecksum) Lizard_XXH32_reset(&d->xxh, 0);
+    /* decoded bytes: one block, plus — linked — the history behind it with room to slide only every 16 MiB */
+    need = d->maxBlockSize + (blockMode == 0 ? 2 * LZF_DICT : 0);
+    if (d->histCap < need) {
+        free(d->hist);
+        d->hist = (uint8_t*)malloc(need);
+        d->histCap = d->hist ? need : 0;
+        if (!d->hist) return LZF_ERR(GENERIC);
+    }
+    d->histFill = 0; d->outStart = d->outEnd = 0; d->inFill = 0; d->inTarget = 0;
+    d->infoValid = 1;
+    return 0;
+}
+
+/* room for `n` more decoded bytes behind the history of a linked frame: when the buffer is full the last 16 MiB slide to its
+ * front (nothing is waiting to be flushed when this is called) */
+static void hist_make_room(LizardF_decompressionContext_t d, size_t n)
+{
+    if (d->histFill + n > d->histCap) {
+        const size_t keep = d->histFill < LZF_DICT ? d->histFill : LZF_DICT;
+        memmove(d->hist, d->hist + d->histFill - keep, keep);
+        d->histFill = keep;
+    }
+}
+
+/* LizardF_decompress, lizard_frame.c:980-1362 */
+size_t LizardF_decompress(LizardF_decompressionContext_t d, void* dstBuffer, size_t* dstSizePtr, const void* srcBuffer, size_t* srcSizePtr,
+                          const LizardF_decompressOptions_t* decompressOptionsPtr)
+{
+    const uint8_t* const srcStart = (const uint8_t*)srcBuffer;
+    const uint8_t* src = srcStart;
+    const uint8_t* const srcEnd = srcStart + *srcSizePtr;
+    uint8_t* const dstStart = (uint8_t*)dstBuffer;
+    uint8_t* dst = dstStart;
+    uint8_t* const dstEnd = dstStart + *dstSizePtr;
+    size_t hint = 1;
+    int more = 1;
+    (void)decompressOptionsPtr;                              /* stableDst: the caller's buffer is never used as history here */
+    *srcSizePtr = 0; *dstSizePtr = 0;
+    if (d->srcExpect && srcStart != d->srcExpect) return LZF_ERR(srcPtr_wrong);                      /* :1004-1006 */
+    while (more) {
+        switch (d->stage) {
+        case DS_HEADER: {
+            /* 5 bytes name the kind of frame and the size of its header: 8 (skippable), 7 or 15 */
+            if (d->smallTarget == 0) { d->smallFill = 0; d->smallTarget = 5; d->infoValid = 0; }
+            {
+                size_t n = d->smallTarget - d->smallFill;
+                if (n > (size_t)(srcEnd - src)) n = (size_t)(srcEnd - src);
+                memcpy(d->small + d->smallFill, src, n);
+                d->smallFill += n; src += n;
+            }
+            if (d->smallFill < d->smallTarget) {
+                hint = ((d->smallTarget < LZF_MIN_HEADER ? LZF_MIN_HEADER : d->smallTarget) - d->smallFill) + 4;   /* rest of the header + a block header */
+                more = 0; break;
+            }
+            if (d->smallTarget == 5) {
+                const uint32_t magic = rd32le(d->small);
+                if ((magic & 0xFFFFFFF0u) == LZF_MAGIC_SKIPPABLE) { d->smallTarget = 8; break; }
+                if (magic != LZF_MAGIC) { d->smallTarget = 0; return LZF_ERR(frameType_unknown); }
+                d->smallTarget = ((d->small[4] >> 3) & 1u) ? LZF_MAX_HEADER : LZF_MIN_HEADER;
+                break;
+            }
+            if (d->smallTarget == 8) {                                                                /* skippable frame: LE32 size, then that many bytes */
+                memset(&d->info, 0, sizeof d->info);
+                d->info.frameType = LizardF_skippableFrame;
+                d->info.contentSize = rd32le(d->small + 4);                                          /* :1303-1304 */
+                d->left = (size_t)d->info.contentSize;
+                d->infoValid = 1;
+                d->smallTarget = 0;
+                d->stage = DS_SKIP;
+                break;
+            }
+            {
+                const size_t e = decode_header(d, d->small, d->smallTarget);
+                d->smallTarget = 0;
+                if (LizardF_isError(e)) return e;
+            }
+            d->stage = DS_BLOCK_HEADER;
+            break;
+        }
+        case DS_BLOCK_HEADER: {
+            const uint8_t* h;
+            uint32_t word;
+            size_t size;
+            if (d->smallTarget == 0 && (size_t)(srcEnd - src) >= 4) { h = src; src += 4; }
+            else {
+                size_t n;
+                if (d->smallTarget == 0) { d->smallFill = 0; d->smallTarget = 4; }
+                n = 4 - d->smallFill;
+                if (n > (size_t)(srcEnd - src)) n = (size_t)(srcEnd - src);
+                memcpy(d->small + d->smallFill, src, n);
+                d->smallFill += n; src += n;
+                if (d->smallFill < 4) { hint = 4 - d->smallFill; more = 0; break; }                   /* :1062-1066 */
+                h = d->small;
+                d->smallTarget = 0;
+            }
+            word = rd32le(h);
+            size = word & 0x7FFFFFFFu;
+            if (size == 0) { d->stage = DS_SUFFIX; break; }                                           /* end mark */
+            if (size > d->maxBlockSize) return LZF_ERR(GENERIC);                                      /* :1076 */
+            if (word & 0x80000000u) { d->left = size; d->stage = DS_RAW; break; }
+            d->inTarget = size; d->inFill = 0;
+            d->stage = DS_BLOCK;
+            if (dst == dstEnd) { hint = size + 4; more = 0; }                                         /* :1083-1086 */
+            break;
+        }
+        case DS_RAW: {                                                                                /* :1090-1112: streams through, piece by piece */
+            size_t n = d->left;
+            if (n > (size_t)(srcEnd - src)) n = (size_t)(srcEnd - src);
+            if (n > (size_t)(dstEnd - dst)) n = (size_t)(dstEnd - dst);
+            if (n) {
+                memcpy(dst, src, n);
+                if (d->info.contentChecksumFlag) Lizard_XXH32_update(&d->xxh, src, n);
+                if (d->info.contentSize) d->remaining -= n;
+                if (d->info.blockMode == LizardF_blockLinked) {                                      /* the bytes are history for later blocks */
+                    hist_make_room(d, n);
+                    memcpy(d->hist + d->histFill, src, n);
+                    d->histFill += n;
+                }
+                src += n; dst += n; d->left -= n;
+            }
+            if (d->left == 0) { d->stage = DS_BLOCK_HEADER; break; }
+            hint = d->left + 4;
+            more = 0;
+            break;
+        }
+        case DS_BLOCK: {
+            const uint8_t* from;
+            int n;
+            if (d->inFill == 0 && (size_t)(srcEnd - src) >= d->inTarget) { from = src; src += d->inTarget; }   /* whole block in the caller's buffer */
+            else {
+                size_t k;
+                if (d->inCap < d->maxBlockSize) {
+                    free(d->in);
+                    d->in = (uint8_t*)malloc(d->maxBlockSize);
+                    d->inCap = d->in ? d->maxBlockSize : 0;
+                    if (!d->in) return LZF_ERR(GENERIC);
+                }
+                k = d->inTarget - d->inFill;
+                if (k > (size_t)(srcEnd - src)) k = (size_t)(srcEnd - src);
+                memcpy(d->in + d->inFill, src, k);
+                d->inFill += k; src += k;
+                if (d->inFill < d->inTarget) { hint = (d->inTarget - d->inFill) + 4; more = 0; break; }   /* :1132-1136 */
+                from = d->in;
+            }
+            if (d->info.blockMode == LizardF_blockLinked) {
+                /* into the internal buffer, right behind the history (a prefix: no offset reaches further than LIZARD_DICT_SIZE back) */
+                size_t dict;
+                hist_make_room(d, d->maxBlockSize);
+                dict = d->histFill < LZF_DICT ? d->histFill : LZF_DICT;
+                n = Lizard_decompress_safe_usingDict((const char*)from, (char*)d->hist + d->histFill, (int)d->inTarget, (int)d->maxBlockSize,
+                                                     (const char*)d->hist + d->histFill - dict, (int)dict);
+                if (n < 0) return LZF_ERR(decompressionFailed);
+                d->outStart = d->histFill; d->outEnd = d->histFill + (size_t)n; d->histFill += (size_t)n;
+                if (d->info.contentChecksumFlag) Lizard_XXH32_update(&d->xxh, d->hist + d->outStart, (size_t)n);
+                if (d->info.contentSize) d->remaining -= (unsigned long long)n;
+                d->stage = DS_FLUSH;
+            } else if ((size_t)(dstEnd - dst) >= d->maxBlockSize) {                                   /* :1148-1170: straight into the caller's buffer */
+                n = Lizard_decompress_safe((const char*)from, (char*)dst, (int)d->inTarget, (int)d->maxBlockSize);
+                if (n < 0) return LZF_ERR(GENERIC);
+                if (d->info.contentChecksumFlag) Lizard_XXH32_update(&d->xxh, dst, (size_t)n);
+                if (d->info.contentSize) d->remaining -= (unsigned long long)n;
+                dst += n;
+                d->stage = DS_BLOCK_HEADER;
+            } else {                                                                                  /* :1172-1206: wait in the internal buffer for room */
+                n = Lizard_decompress_safe((const char*)from, (char*)d->hist, (int)d->inTarget, (int)d->maxBlockSize);
+                if (n < 0) return LZF_ERR(decompressionFailed);
+                if (d->info.contentChecksumFlag) Lizard_XXH32_update(&d->xxh, d->hist, (size_t)n);
+                if (d->info.contentSize) d->remaining -= (unsigned long long)n;
+                d->outStart = 0; d->outEnd = (size_t)n;
+                d->stage = DS_FLUSH;
+            }
+            d->inFill = 0;
+            break;
+        }
+        case DS_FLUSH: {                                                                              /* :1208-1228 */
+            size_t n = d->outEnd - d->outStart;
+            if (n > (size_t)(dstEnd - dst)) n = (size_t)(dstEnd - dst);
+            memcpy(dst, d->hist + d->outStart, n);
+            d->outStart += n; dst += n;
+            if (d->outStart == d->outEnd) { d->stage = DS_BLOCK_HEADER; break; }
+            hint = 4;
+            more = 0;
+            break;
+        }
+        case DS_SUFFIX: {                                                                             /* :1230-1272 */
+            if (d->smallTarget == 0 && d->remaining) return LZF_ERR(frameSize_wrong);
+            if (!d->info.contentChecksumFlag) { hint = 0; d->stage = DS_HEADER; more = 0; break; }
+            {
+                size_t n;
+                if (d->smallTarget == 0) { d->smallFill = 0; d->smallTarget = 4; }
+                n = 4 - d->smallFill;
+                if (n > (size_t)(srcEnd - src)) n = (size_t)(srcEnd - src);
+                memcpy(d->small + d->smallFill, src, n);
+                d->smallFill += n; src += n;
+                if (d->smallFill < 4) { hint = 4 - d->smallFill; more = 0; break; }
+                d->smallTarget = 0;
+                if (rd32le(d->small) != Lizard_XXH32_digest(&d->xxh)) return LZF_ERR(contentChecksum_invalid);
+            }
+            hint = 0; d->stage = DS_HEADER; more = 0;
+            break;
+        }
+        case DS_SKIP: {                                                                               /* :1309-1319 */
+            size_t n = d->left;
+            if (n > (size_t)(srcEnd - src)) n = (size_t)(srcEnd - src);
+            src += n; d->left -= n;
+            hint = d->left;
+            more = 0;
+            if (!hint) d->stage = DS_HEADER;
+            break;
+        }
+        default: return LZF_ERR(GENERIC);
+        }
+    }
+    d->srcExpect = src < srcEnd ? src : NULL;                                                        /* :1354-1357 */
+    *srcSizePtr = (size_t)(src - srcStart);
+    *dstSizePtr = (size_t)(dst - dstStart);
+    return hint;
+}
+
+/* LizardF_getFrameInfo, lizard_frame.c:871-894 */
+size_t LizardF_getFrameInfo(LizardF_decompressionContext_t d, LizardF_frameInfo_t* frameInfoPtr, const void* srcBuffer, size_t* srcSizePtr)
+{
+    if (d->stage != DS_HEADER) {                                                                      /* already decoded: report it, consume nothing */
+        size_t o = 0, i = 0;
+        const uint8_t* const keep = d->srcExpect;
+        size_t hint;
+        *srcSizePtr = 0;
+        *frameInfoPtr = d->info;
+        d->srcExpect = NULL;
+        hint = LizardF_decompress(d, NULL, &o, NULL, &i, NULL);
+        d->srcExpect = keep;
+        return hint;
+    }
+    {
+        const uint8_t* p = (const uint8_t*)srcBuffer;
+        size_t hSize, o = 0, hint;
+        if (*srcSizePtr < 5) { *srcSizePtr = 0; return LZF_ERR(frameHeader_incomplete); }            /* LizardF_headerSize, :725-745 */
+        if ((rd32le(p) & 0xFFFFFFF0u) == LZF_MAGIC_SKIPPABLE) hSize = 8;
+        else if (rd32le(p) != LZF_MAGIC) { *srcSizePtr = 0; return LZF_ERR(frameType_unknown); }
+        else hSize = ((p[4] >> 3) & 1u) ? LZF_MAX_HEADER : LZF_MIN_HEADER;
+        if (*srcSizePtr < hSize) { *srcSizePtr = 0; return LZF_ERR(frameHeader_incomplete); }
+        *srcSizePtr = hSize;
+        d->smallTarget = 0;                                                                           /* the header is read from srcBuffer, whole */
+        hint = LizardF_decompress(d, NULL, &o, srcBuffer, srcSizePtr, NULL);
+        if (LizardF_isError(hint)) return hint;
+        if (!d->infoValid) return LZF_ERR(frameHeader_incomplete);
+        *frameInfoPtr = d->info;
+        return hint;
+    }
 }

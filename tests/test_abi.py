@@ -20,14 +20,49 @@ def lib():
 def declared_functions():
     text = open(os.path.join(util.ROOT, "include", "lizard_amd.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(Lizard(?:GPU)?_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(Lizard(?:GPU|F)?_\w+)\s*\(", text)))
 
 
 def test_exports_every_declared_symbol(lib):
     names = declared_functions()
-    assert "Lizard_compress" in names and "LizardGPU_compressBlocks_device" in names
+    assert "Lizard_compress" in names and "LizardGPU_compressBlocks_device" in names and "LizardF_compressUpdate" in names
+    assert "Lizard_decompress_safe_usingDict" in names and "Lizard_XXH64_digest" in names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/lizard_amd.h but not exported"
+
+
+def exported():
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    return sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+
+
+def test_exports_nothing_else(lib):
+    """The dynamic symbol table is the declared surface and nothing more (lizard_amd/csrc/exports.map): no internal seam
+    (lzk_*, lzgpu_*) leaks into a process that links the library as its liblizard."""
+    assert exported() == declared_functions()
+
+
+def test_exports_cover_the_reference_library(lib):
+    """Every name of the reference's own export list (lib/dll/liblizard.def), of lib/lizard_frame.h, and every Lizard_* /
+    LizardF_* / Lizard_XXH* symbol the reference's programs import (recorded with nm -u from programs/*.o, tests/fuzzer.o,
+    frametest.o, fullbench.o)."""
+    need = """Lizard_compress Lizard_compressBound Lizard_compress_continue Lizard_compress_extState Lizard_createStream
+      Lizard_createStreamDecode Lizard_decompress_safe Lizard_decompress_safe_continue Lizard_decompress_safe_partial
+      Lizard_decompress_safe_usingDict Lizard_freeStream Lizard_freeStreamDecode Lizard_loadDict Lizard_resetStream Lizard_saveDict
+      Lizard_setStreamDecode Lizard_sizeofState
+      Lizard_compress_MinLevel Lizard_compress_extState_MinLevel Lizard_createStream_MinLevel Lizard_resetStream_MinLevel
+      Lizard_sizeofState_MinLevel Lizard_decompress_safe_forceExtDict Lizard_versionNumber
+      LizardF_isError LizardF_getErrorName LizardF_compressFrameBound LizardF_compressFrame LizardF_createCompressionContext
+      LizardF_freeCompressionContext LizardF_compressBegin LizardF_compressBound LizardF_compressUpdate LizardF_flush LizardF_compressEnd
+      LizardF_createDecompressionContext LizardF_freeDecompressionContext LizardF_getFrameInfo LizardF_decompress
+      Lizard_XXH32 Lizard_XXH32_reset Lizard_XXH32_update Lizard_XXH32_digest Lizard_XXH64 Lizard_XXH64_reset Lizard_XXH64_update
+      Lizard_XXH64_digest""".split()
+    have = set(exported())
+    assert not [n for n in need if n not in have]
+    if os.path.exists("/root/reference/lib/dll/liblizard.def"):
+        text = open("/root/reference/lib/dll/liblizard.def").read()
+        names = [l.strip() for l in text.split("EXPORTS")[1].splitlines() if l.strip()]
+        assert len(names) == 17 and not [n for n in names if n not in have]
 
 
 def test_bound_and_version_without_gpu(lib):
@@ -67,15 +102,13 @@ REF = "/root/reference"
 
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "programs")), reason="reference checkout not present (GPU box)")
 def test_reference_cli_links_against_library(lib, tmp_path):
-    """INTEGRATION.md section 1, literally: the reference's own CLI objects (bench, lizardio, lizardcli, datagen) plus
-    its decoder / frame layer / xxhash, linked against liblizard_amd.so INSTEAD of lizard_compress.o and the
-    entropy encoders.  Everything is compiled into a temporary directory from the sources where they lie.
+    """INTEGRATION.md section 1, literally: the reference's own CLI objects (bench, lizardio, lizardcli, datagen) linked
+    against liblizard_amd.so and nothing else — block compressor, decoder, frame layer and xxhash are the product's.
+    Everything is compiled into a temporary directory from the sources where they lie.
     Without a GPU the library must fail loudly and the frame layer then stores the blocks raw: the file still
-    round-trips through the reference decoder."""
+    round-trips (through this library's frame decoder)."""
     import torch
-    srcs = ["programs/bench.c", "programs/lizardio.c", "programs/lizardcli.c", "programs/datagen.c",
-            "lib/lizard_decompress.c", "lib/lizard_frame.c", "lib/xxhash/xxhash.c", "lib/entropy/entropy_common.c",
-            "lib/entropy/fse_decompress.c", "lib/entropy/huf_decompress.c"]
+    srcs = ["programs/bench.c", "programs/lizardio.c", "programs/lizardcli.c", "programs/datagen.c"]   # and NO object of the reference's lib/
     objs = []
     for f in srcs:
         o = str(tmp_path / (os.path.basename(f)[:-2] + ".o"))
@@ -159,17 +192,56 @@ def test_reference_cli_one_byte_tail_block(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prog,args", [("fuzzer_amd", ["-T10s"]), ("frametest_amd", ["-T10s"])])
-def test_reference_test_programs_on_the_gpu_library(prog, args):
+@pytest.mark.parametrize("prog,args", [("fuzzer_amd", ["-T10s"]), ("frametest_amd", ["-T10s"]), ("fullbench_amd", ["-i1"])])
+def test_reference_test_programs_on_the_gpu_library(prog, args, tmp_path):
     """SURVEY.md section 7 step 2 acceptance: the reference's own fuzzer (tests/fuzzer.c: bounds behaviour, limited
-    output, dictionaries, streaming; levels 10 and 17) and frametest (tests/frametest.c: every frame preference,
-    linked and independent blocks, random segmentation; levels 10-49 clamp/dispatch) built by oracle/Makefile against
-    liblizard_amd.so instead of lib/lizard_compress.c.  They check round trips and error behaviour, not bytes; linked
+    output, dictionaries, streaming; levels 10 and 17), frametest (tests/frametest.c: every frame preference,
+    linked and independent blocks, random segmentation; levels 10-49 clamp/dispatch) and fullbench (tests/fullbench.c:
+    every public compression and decompression entry point on a file) built by oracle/Makefile against liblizard_amd.so
+    ALONE — no object of the reference's lib/ is linked.  They check round trips and error behaviour, not bytes; linked
     mode is served by history-free blocks (include/lizard_amd.h, Lizard_compress_continue)."""
     exe = os.path.join(util.ROOT, "oracle", "_ref", prog)
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/%s not built" % prog)
-    r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600)
+    ldd = subprocess.check_output(["ldd", exe]).decode()
+    assert "liblizard_amd.so" in ldd and "liblizard_ref" not in ldd
+    undefined = subprocess.check_output(["nm", "-u", exe]).decode()
+    assert "Lizard_decompress_safe" in undefined and ("LizardF_decompress" in undefined or prog == "fuzzer_amd")   # decoder and frames come from the product
+    if prog == "fullbench_amd":
+        f = tmp_path / "in.bin"
+        f.write_bytes(util.datagen(3 << 20, 0.5, 0.0, 3))
+        args = args + [str(f)]
+    r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=900)
     tail = (r.stdout + r.stderr)[-2000:]
     assert r.returncode == 0, tail
     assert "no CPU fallback" not in r.stderr or prog == "frametest_amd", tail
+
+
+@pytest.mark.gpu
+def test_liz_files_equal_the_stock_cli(tmp_path):
+    """The reference's CLI linked against the product alone writes, at levels 10 / 21 / 30 and several block sizes, the
+    very .liz file the STOCK CLI (reference library inside, oracle/_ref/lizard_cli_ref) writes — and each decodes the other's."""
+    amd = os.path.join(util.ROOT, "oracle", "_ref", "lizard_cli_amd")
+    ref = os.path.join(util.ROOT, "oracle", "_ref", "lizard_cli_ref")
+    if not (os.path.exists(amd) and os.path.exists(ref)):
+        pytest.skip("oracle/_ref CLIs not built")
+    data = util.datagen((5 << 20) + 4321, 0.5, 0.0, 41)
+    (tmp_path / "in.bin").write_bytes(data)
+    for level, extra in ((10, []), (21, ["-B2"]), (30, ["-B1"]), (10, ["-B3", "--content-size"]), (30, ["--no-frame-crc"])):
+        a, b = tmp_path / "a.liz", tmp_path / "b.liz"
+        for exe, out in ((amd, a), (ref, b)):
+            r = subprocess.run([exe, f"-{level}", "-f"] + extra + [str(tmp_path / "in.bin"), str(out)], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+        assert a.read_bytes() == b.read_bytes(), (level, extra)
+        for exe, src in ((amd, b), (ref, a)):
+            back = tmp_path / "back.bin"
+            r = subprocess.run([exe, "-d", "-f", str(src), str(back)], capture_output=True, text=True)
+            assert r.returncode == 0 and back.read_bytes() == data, (level, extra, r.stderr)
+    # linked blocks (-BD): valid, decodable by the stock decoder; the bytes are those of independent blocks (DESIGN.md section 9)
+    a = tmp_path / "linked.liz"
+    r = subprocess.run([amd, "-10", "-BD", "-B1", "-f", str(tmp_path / "in.bin"), str(a)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (a.read_bytes()[4] >> 5) & 1 == 0
+    back = tmp_path / "back.bin"
+    r = subprocess.run([ref, "-d", "-f", str(a), str(back)], capture_output=True, text=True)
+    assert r.returncode == 0 and back.read_bytes() == data
