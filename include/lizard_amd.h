@@ -277,8 +277,9 @@ int  LizardGPU_commDestroy(void);
  * library received them; allGather is in place when send == recv + rank*count, as ncclAllGather; every call returns 0 or a
  * negative LIZARDGPU_ERR_*).  RCCL fills it by default — resolved from a copy the process has already mapped (torch's in a
  * torchrun job) before librccl.so.1 is loaded, LizardGPU_rcclShared() = 1 / 0 / -1 (not resolved yet).  LizardGPU_setCollectives
- * installs another transport (NULL: back to RCCL); with one installed, LizardGPU_compressBlocks_sharded passes the rank index
- * as `comm` and makes no communicator.  The exchange logic itself (lizard_amd/csrc/lizard_shard_core.h) is transport-agnostic:
+ * installs another transport (NULL: back to RCCL; a table with a NULL member is refused); with one installed NO RCCL is involved:
+ * LizardGPU_compressBlocks_sharded and LizardGPU_gatherSizes_device pass the rank index as `comm`, and LizardGPU_commInitRank only
+ * records rank and rank count (its id argument is ignored).  The exchange logic itself (lizard_amd/csrc/lizard_shard_core.h) is transport-agnostic:
  * tests/shard_fake.cpp runs it with 2 and 3 ranks over shared memory on a CPU. */
 typedef struct {
     int (*allGather)(const void* send, void* recv, size_t count, void* comm, void* stream);
@@ -312,6 +313,15 @@ float LizardGPU_lastKernelMs(void);
 
 /* Number of resident waves (= blocks compressed concurrently) the launcher uses on this device. */
 int LizardGPU_residentWaves(void);
+
+/* The one-block entry points of part 1 (Lizard_compress, _extState, _continue) are COMBINED: callers that arrive while a launch is
+ * in flight leave together in the next one — one ragged batch, one block per CU — instead of queueing behind a lock, so N host
+ * threads compress N blocks per launch (lizard_amd/csrc/lizard_pipeline_host.c).  Launches made / blocks carried so far on the
+ * selected device (either pointer may be NULL); 0 or -LIZARDGPU_ERR_*. */
+int LizardGPU_combinerStats(unsigned long long* batches, unsigned long long* blocks);
+/* Tuning aid: where the batches' time went, seconds since the process started — [0] waiting for the device context, [1] the
+ * members' copy-in, [2] the GPU part (H2D, kernel, compaction, D2H), [3] until the last member had copied out. */
+int LizardGPU_combinerProfile(double out[4]);
 
 /* =====================================================================================================
  * Part 3 — frame production on the batched GPU path.

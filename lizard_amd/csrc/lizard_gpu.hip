@@ -23,7 +23,8 @@ typedef LzStage Stage;                                 // lizard_gpu_ctx.h (plai
 typedef LzCtx Ctx;
 Ctx g_ctx[LZ_MAX_DEVICES];
 struct CtxDefaults {                                   // (the contexts are zero-initialised statics; these fields start elsewhere)
-    CtxDefaults() { for (Ctx& c : g_ctx) { pthread_mutex_init(&c.mu, nullptr); c.device = -1; c.laneOrderOk = 1; c.hostKernelMs = -1.0f; } }
+    CtxDefaults() { for (Ctx& c : g_ctx) { pthread_mutex_init(&c.mu, nullptr); pthread_mutex_init(&c.comb.mu, nullptr); pthread_cond_init(&c.comb.cv, nullptr);
+                                           c.device = -1; c.laneOrderOk = 1; c.hostKernelMs = -1.0f; } }
 } g_ctx_defaults;
 int g_default_device = 0;                              // process default (the last LizardGPU_setDevice of any thread)
 pthread_mutex_t g_sel_mu = PTHREAD_MUTEX_INITIALIZER;
@@ -155,6 +156,7 @@ void ctx_release(Ctx& c)
         if (s.stream) (void)hipStreamDestroy(s.stream);
         memset(&s, 0, sizeof s);
     }
+    lzk_combiner_free(&c);
     if (c.tables) (void)hipFree(c.tables);
     if (c.pfTables) (void)hipFree(c.pfTables);
     if (c.hcSlots) (void)hipFree(c.hcSlots);
@@ -184,8 +186,11 @@ size_t level_max_block(int lv)
     return 0;
 }
 
+// d_srcSizes / d_srcOffsets (may be nullptr, both or neither): a ragged batch — block b is d_srcSizes[b] bytes (1..blockSize) at
+// d_src + d_srcOffsets[b]; lastBlockSize is ignored then (pass blockSize).
 int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t lastBlockSize, void* d_dst,
-           size_t dstStride, u32* d_sizes, int level, hipStream_t stream, hipEvent_t k0 = nullptr, hipEvent_t k1 = nullptr)
+           size_t dstStride, u32* d_sizes, int level, hipStream_t stream, hipEvent_t k0 = nullptr, hipEvent_t k1 = nullptr,
+           const u32* d_srcSizes = nullptr, const u64* d_srcOffsets = nullptr)
 {
     const int lv = clamp_level(level);
     if (!LizardGPU_levelSupported(lv)) { snprintf(t_err, sizeof t_err, "level %d has no GPU kernel", lv); return -LIZARDGPU_ERR_LEVEL; }
@@ -208,6 +213,7 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
     a.src = (const u8*)d_src; a.blockSize = blockSize; a.nBlocks = (u32)nBlocks; a.lastBlockSize = (u32)lastBlockSize;
     a.dst = (u8*)d_dst; a.dstStride = dstStride; a.sizes = d_sizes; a.level = (u32)lv;
     a.scratch = c.scratch; a.counter = c.counter; a.tables = nullptr; a.tableStride = 0; a.tableSlots = 0xFFFFFFFFu;
+    a.srcSizes = d_srcSizes; a.srcOffsets = d_srcOffsets; a.activeWaves = 0xFFFFFFFFu;
     // one workgroup of W waves per CU; small batches launch only as many workgroups as they have blocks for
     const bool hcLevel = (lv >= 13 && lv <= 17) || (lv >= 34 && lv <= 38);
     const bool fastMixed = blockSize <= (4u << 20);                         // global-table waves hold 22-bit positions
@@ -249,6 +255,14 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
     if (!perGroup) perGroup = W;
     u32 grid = (u32)((nBlocks + perGroup - 1) / perGroup);
     if (grid > (u32)c.cus) grid = (u32)c.cus;
+#if LZ_SPREAD_SMALL
+    // A launch with fewer blocks than the chip has block-claiming waves is spread over ALL CUs, ceil(nBlocks / grid) claiming
+    // waves per workgroup, instead of filling nBlocks / perGroup CUs to the brim: 256 blocks are 256 CUs x 1 wave, not 20 x 13.
+    if (nBlocks < (size_t)c.cus * perGroup) {
+        grid = nBlocks < (size_t)c.cus ? (u32)nBlocks : (u32)c.cus;
+        a.activeWaves = (u32)((nBlocks + grid - 1) / grid);
+    }
+#endif
     // The scratch arena, the tables and the block counter are shared by all launches on this device: a launch
     // on another stream first waits (on the GPU) for the previous one to finish.
     if (c.timed) LZ_HIP(hipStreamWaitEvent(stream, c.ev1, 0));
@@ -364,9 +378,11 @@ void LizardGPU_shutdown(void)
     if (hipGetDevice(&saved) != hipSuccess) saved = -1;
     for (int d = 0; d < LZ_MAX_DEVICES; d++) {
         Ctx& c = g_ctx[d];
+        lzk_combiner_quiesce(&c);                       // no batch of one-block callers is between its launch and its copy-out
         pthread_mutex_lock(&c.mu);
         ctx_release(c);
         pthread_mutex_unlock(&c.mu);
+        lzk_combiner_resume(&c);
     }
     lz_shard_shutdown();
     if (saved >= 0) (void)hipSetDevice(saved);
@@ -396,9 +412,23 @@ char* lzk_err(void) { return t_err; }
 int   lzk_ctx_init(LzCtx* c) { return ctx_init(*c); }
 int   lzk_clamp_level(int level) { return clamp_level(level); }
 int   lzk_launch(LzCtx* c, const void* d_src, size_t nBlocks, size_t blockSize, size_t lastBlockSize, void* d_dst, size_t dstStride,
-                 uint32_t* d_sizes, int level, hipStream_t stream, hipEvent_t k0, hipEvent_t k1)
+                 uint32_t* d_sizes, int level, hipStream_t stream, hipEvent_t k0, hipEvent_t k1, const uint32_t* d_srcSizes,
+                 const uint64_t* d_srcOffsets)
 {
-    return launch(*c, d_src, nBlocks, blockSize, lastBlockSize, d_dst, dstStride, d_sizes, level, stream, k0, k1);
+    return launch(*c, d_src, nBlocks, blockSize, lastBlockSize, d_dst, dstStride, d_sizes, level, stream, k0, k1, d_srcSizes, (const u64*)d_srcOffsets);
+}
+LzCtx* lzk_ctx_peek(void)
+{
+    int count = 0;
+    t_err[0] = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        snprintf(t_err, sizeof t_err, "no HIP device visible");
+        return nullptr;
+    }
+    const int dev = selected_device();
+    if (dev < 0 || dev >= count || dev >= LZ_MAX_DEVICES) { snprintf(t_err, sizeof t_err, "device %d out of range (%d visible)", dev, count); return nullptr; }
+    return &g_ctx[dev];
 }
 int   lzk_launch_decompress(LzCtx* c, const void* d_src, const uint64_t* d_offsets, size_t srcStride, const uint32_t* d_srcSizes,
                             size_t nBlocks, void* d_dst, size_t dstStride, uint32_t* d_outSizes, hipStream_t stream)

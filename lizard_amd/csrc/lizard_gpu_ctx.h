@@ -26,6 +26,23 @@ typedef struct LzStage {
     uint32_t* d_sizes;  uint64_t* d_offsets;  size_t d_meta_cap;
 } LzStage;
 
+/* The combiner of the one-block entry points (Lizard_compress & co, lizard_pipeline_host.c): callers that arrive while a batch
+ * is in flight queue up and leave together in the next launch.  Own staging and stream: the members of a batch copy their input
+ * into h_in and their output out of h_out themselves, outside the context lock. */
+struct LzOneJob;
+typedef struct LzCombine {
+    pthread_mutex_t mu;
+    pthread_cond_t  cv;
+    struct LzOneJob *head, *tail;       /* callers waiting for a batch */
+    int   busy;                         /* a batch is under way: from the moment its leader takes it until its last member has copied out */
+    int   pendingIn, pendingOut;        /* members of the current batch that still have to copy in / out */
+    LzStage st;                         /* staging of the current batch */
+    uint32_t* d_srcSizes; uint64_t* d_srcOffsets; uint32_t* h_srcSizes; uint64_t* h_srcOffsets; size_t raggedCap;
+    unsigned long long batches, jobs;   /* statistics (LizardGPU_combinerStats) */
+    double tLock, tCopyIn, tGpu, tOut;  /* seconds spent by leaders: waiting for the context, members' copy-in, GPU part, until the last member left */
+    double tBusySince;
+} LzCombine;
+
 typedef struct LzCtx {
     int   ready;
     int   device;
@@ -41,6 +58,7 @@ typedef struct LzCtx {
     int   laneOrderOk;          /* self-check at context creation: lanes of one DS atomic are served in lane order */
     float hostKernelMs;         /* sum over the chunks of the last host-buffer call (< 0: last call was a device call) */
     LzStage stage[LZ_STAGES];
+    LzCombine comb;
     pthread_mutex_t mu;
 } LzCtx;
 
@@ -58,9 +76,16 @@ char* lzk_err(void);                                        /* the calling threa
 int   lzk_ctx_init(LzCtx* c);
 int   lzk_clamp_level(int level);
 /* the block kernels over nBlocks blocks resident at d_src (launcher of LizardGPU_compressBlocks_device); k0 / k1 (may be NULL)
- * are recorded around the kernel */
+ * are recorded around the kernel; d_srcSizes / d_srcOffsets (may be NULL): a ragged batch, block b = d_srcSizes[b] bytes at d_src + d_srcOffsets[b] */
 int   lzk_launch(LzCtx* c, const void* d_src, size_t nBlocks, size_t blockSize, size_t lastBlockSize, void* d_dst, size_t dstStride,
-                 uint32_t* d_sizes, int level, hipStream_t stream, hipEvent_t k0, hipEvent_t k1);
+                 uint32_t* d_sizes, int level, hipStream_t stream, hipEvent_t k0, hipEvent_t k1, const uint32_t* d_srcSizes,
+                 const uint64_t* d_srcOffsets);
+/* the calling thread's selected device's context WITHOUT locking it (NULL: no device, the error text is set) */
+LzCtx* lzk_ctx_peek(void);
+/* lizard_pipeline_host.c: release the combiner's buffers (context locked, no batch under way); keep batches out during a shutdown */
+void  lzk_combiner_free(LzCtx* c);
+void  lzk_combiner_quiesce(LzCtx* c);
+void  lzk_combiner_resume(LzCtx* c);
 int   lzk_launch_decompress(LzCtx* c, const void* d_src, const uint64_t* d_offsets, size_t srcStride, const uint32_t* d_srcSizes,
                             size_t nBlocks, void* d_dst, size_t dstStride, uint32_t* d_outSizes, hipStream_t stream);
 /* exclusive scan of the record sizes + compaction of the valid bytes into d_packed (lz_pack.h); mode: LZK_PACK_* */

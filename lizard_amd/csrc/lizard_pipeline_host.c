@@ -9,9 +9,11 @@
  * calling thread stages and issues chunk after chunk; a drain thread follows it chunk by chunk — waits for the sizes, requests
  * exactly the packed bytes, waits for them and hands them to the sink.  With LZ_STAGES chunks in flight neither side waits for
  * the other's host copies, and the two PCIe directions run side by side. */
+#define _POSIX_C_SOURCE 200809L
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../../include/lizard_amd.h"
 #include "lizard_gpu_ctx.h"
@@ -134,7 +136,7 @@ static int stage_issue(LzCtx* c, LzStage* s, const HostJob* j, ChunkState* ch, i
     if (prevUp) LZ_HIP(hipStreamWaitEvent(s->stream, prevUp, 0));
     LZ_HIP(hipMemcpyAsync(s->d_in, from, ch->inBytes, hipMemcpyHostToDevice, s->stream));
     LZ_HIP(hipEventRecord(s->up, s->stream));
-    if ((rc = lzk_launch(c, s->d_in, ch->nb, j->blockSize, last, s->d_slots, slot, s->d_sizes, j->level, s->stream, s->k0, s->k1))) return rc;
+    if ((rc = lzk_launch(c, s->d_in, ch->nb, j->blockSize, last, s->d_slots, slot, s->d_sizes, j->level, s->stream, s->k0, s->k1, NULL, NULL))) return rc;
     lzk_pack_launch(s->d_in, s->d_slots, slot, s->d_sizes, s->d_offsets, s->d_packed, (uint32_t)ch->nb, (uint32_t)j->blockSize, (uint32_t)last, j->mode, s->stream);
     LZ_HIP(hipGetLastError());
     LZ_HIP(hipMemcpyAsync(s->h_sizes, s->d_sizes, ch->nb * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
@@ -362,63 +364,274 @@ int lzgpu_frame_records(const void* src, size_t nBlocks, size_t blockSize, size_
     return rc;
 }
 
-/* Internal shim for the one-block reference entry points (lizard_host.c): compress one host block, honouring the reference's
- * maxDstSize contract: returns the compressed size, 0 if it does not fit (reference lib/lizard_compress.c:543-546), < 0 on a GPU
- * failure. */
-static int compress_one_locked(LzCtx* c, const void* src, int srcSize, void* dst, int maxDstSize, int level)
+/* ---- the one-block entry points (lizard_host.c: Lizard_compress, _extState, _continue) ----
+ *
+ * One block is one wavefront: ~3 ms for 256 KiB whatever else the chip is doing, so a caller that compresses block after block
+ * gets ~80 MB/s, and N threads doing so behind a lock would share those 80 MB/s.  The COMBINER makes their calls leave together:
+ * a caller that finds no batch under way becomes the LEADER of one — it takes every caller of its level that is waiting (itself
+ * included), lays their inputs out back to back in pinned staging, lets every member copy its own input in (the host copies of a
+ * batch run on the members' own threads, side by side), launches ONE ragged batch (per-block sizes and offsets, LzBatch::srcSizes /
+ * ::srcOffsets; blocks spread one per CU, LzBatch::activeWaves), packs the valid bytes on the device, fetches them with one D2H,
+ * and every member copies its own output out and returns.  Callers that arrive meanwhile queue up for the next batch; the next
+ * leader is whichever of them wakes first.  N concurrent callers get N blocks per launch instead of one: the aggregate rate is
+ * N x the one-block rate until the PCIe copies matter.
+ *
+ * Each block is compressed exactly as by LizardGPU_compressBlocks_* (same kernels, zero-state semantics), and the reference's
+ * maxDstSize contract is applied per member: compressed size, 0 if it does not fit (reference lib/lizard_compress.c:543-546),
+ * < 0 on a GPU failure. */
+typedef struct LzOneJob {
+    const void* src; int srcSize; void* dst; int maxDst; int level;
+    int state;                                  /* JOB_* */
+    int result;
+    size_t inOff;                               /* my input's place in the batch's staging */
+    const uint8_t* out; uint32_t csize;         /* my compressed block in the batch's pinned output */
+    char errText[LZK_ERR_BYTES];
+    struct LzOneJob* next;
+} LzOneJob;
+enum { JOB_QUEUED = 0, JOB_COPY_IN, JOB_COPIED_IN, JOB_RESULT, JOB_FAILED };
+#define LZ_ONE_MAX_JOBS   1024                  /* members per batch */
+#define LZ_ONE_MAX_BYTES  ((size_t)1 << 30)     /* input bytes per batch */
+
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + (double)t.tv_nsec * 1e-9; }
+
+/* the GPU part of a batch: inputs are in comb.st.h_in at job->inOff; on success every job has out / csize */
+static int batch_on_gpu(LzCtx* c, LzOneJob** jobs, int n, size_t inBytes, size_t maxSize, int level)
 {
-    LzStage* s = &c->stage[0];
-    const size_t slot = ((size_t)LIZARD_COMPRESSBOUND(srcSize) + 63) & ~(size_t)63;
-    uint32_t csize;
+    LzCombine* k = &c->comb;
+    LzStage* s = &k->st;
+    const size_t slot = ((size_t)LIZARD_COMPRESSBOUND((int)maxSize) + 63) & ~(size_t)63;
+    size_t total;
+    int i, rc;
+    for (i = 0; i < n; i++) { k->h_srcSizes[i] = (uint32_t)jobs[i]->srcSize; k->h_srcOffsets[i] = jobs[i]->inOff; }
+    LZ_HIP(hipMemcpyAsync(k->d_srcSizes, k->h_srcSizes, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    LZ_HIP(hipMemcpyAsync(k->d_srcOffsets, k->h_srcOffsets, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream));
+    LZ_HIP(hipMemcpyAsync(s->d_in, s->h_in, inBytes, hipMemcpyHostToDevice, s->stream));
+    c->hostKernelMs = -1.0f;
+    if ((rc = lzk_launch(c, s->d_in, (size_t)n, maxSize, maxSize, s->d_slots, slot, s->d_sizes, level, s->stream, NULL, NULL, k->d_srcSizes, k->d_srcOffsets))) return rc;
+    /* the compaction writes the valid bytes STRAIGHT INTO the pinned host buffer (posted PCIe writes, coalesced 16-byte stores):
+     * no separate D2H of the payload and no host round trip between "sizes known" and "payload requested" */
+    {
+        void* d_out = NULL;
+        LZ_HIP(hipHostGetDevicePointer(&d_out, s->h_out, 0));
+        lzk_pack_launch(s->d_in, s->d_slots, slot, s->d_sizes, s->d_offsets, d_out, (uint32_t)n, (uint32_t)maxSize, (uint32_t)maxSize, LZK_PACK_PAYLOAD, s->stream);
+    }
+    LZ_HIP(hipGetLastError());
+    LZ_HIP(hipMemcpyAsync(s->h_sizes, s->d_sizes, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    LZ_HIP(hipMemcpyAsync(s->h_offsets, s->d_offsets, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
+    LZ_HIP(hipStreamSynchronize(s->stream));
+    total = (size_t)s->h_offsets[n];
+    (void)total;
+    for (i = 0; i < n; i++) { jobs[i]->out = s->h_out + s->h_offsets[i]; jobs[i]->csize = s->h_sizes[i]; }
+    return 0;
+}
+
+static int batch_buffers(LzCtx* c, int n, size_t inBytes, size_t maxSize)
+{
+    LzCombine* k = &c->comb;
+    LzStage* s = &k->st;
+    const size_t slot = ((size_t)LIZARD_COMPRESSBOUND((int)maxSize) + 63) & ~(size_t)63;
     int rc = lzk_ctx_init(c);
     if (rc) return rc;
-    if (srcSize == 0) {                 /* reference: level byte only (lizard_compress.c:488-494) */
+    if (!s->stream) LZ_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    if ((rc = ensure_dev((void**)&s->d_in, &s->d_in_cap, inBytes + 64))) return rc;
+    if ((rc = ensure_dev((void**)&s->d_slots, &s->d_slots_cap, (size_t)n * slot))) return rc;
+    if ((rc = ensure_pinned((void**)&s->h_in, &s->h_in_cap, inBytes + 64))) return rc;
+    if ((rc = ensure_pinned((void**)&s->h_out, &s->h_out_cap, (size_t)n * slot))) return rc;
+    if (k->raggedCap < (size_t)n + 1) {
+        const size_t cap = (size_t)n + 65;
+        if (s->d_sizes) { (void)hipFree(s->d_sizes); s->d_sizes = NULL; }
+        if (s->d_offsets) { (void)hipFree(s->d_offsets); s->d_offsets = NULL; }
+        if (k->d_srcSizes) { (void)hipFree(k->d_srcSizes); k->d_srcSizes = NULL; }
+        if (k->d_srcOffsets) { (void)hipFree(k->d_srcOffsets); k->d_srcOffsets = NULL; }
+        if (s->h_sizes) { (void)hipHostFree(s->h_sizes); s->h_sizes = NULL; }
+        if (s->h_offsets) { (void)hipHostFree(s->h_offsets); s->h_offsets = NULL; }
+        if (k->h_srcSizes) { (void)hipHostFree(k->h_srcSizes); k->h_srcSizes = NULL; }
+        if (k->h_srcOffsets) { (void)hipHostFree(k->h_srcOffsets); k->h_srcOffsets = NULL; }
+        k->raggedCap = 0;
+        LZ_HIP(hipMalloc((void**)&s->d_sizes, cap * sizeof(uint32_t)));
+        LZ_HIP(hipMalloc((void**)&s->d_offsets, cap * sizeof(uint64_t)));
+        LZ_HIP(hipMalloc((void**)&k->d_srcSizes, cap * sizeof(uint32_t)));
+        LZ_HIP(hipMalloc((void**)&k->d_srcOffsets, cap * sizeof(uint64_t)));
+        LZ_HIP(hipHostMalloc((void**)&s->h_sizes, cap * sizeof(uint32_t), hipHostMallocDefault));
+        LZ_HIP(hipHostMalloc((void**)&s->h_offsets, cap * sizeof(uint64_t), hipHostMallocDefault));
+        LZ_HIP(hipHostMalloc((void**)&k->h_srcSizes, cap * sizeof(uint32_t), hipHostMallocDefault));
+        LZ_HIP(hipHostMalloc((void**)&k->h_srcOffsets, cap * sizeof(uint64_t), hipHostMallocDefault));
+        k->raggedCap = cap;
+    }
+    return 0;
+}
+
+void lzk_combiner_free(LzCtx* c)                /* context locked, no batch under way (lzk_combiner_quiesce) */
+{
+    LzCombine* k = &c->comb;
+    LzStage* s = &k->st;
+    if (s->h_in) (void)hipHostFree(s->h_in);
+    if (s->h_out) (void)hipHostFree(s->h_out);
+    if (s->h_sizes) (void)hipHostFree(s->h_sizes);
+    if (s->h_offsets) (void)hipHostFree(s->h_offsets);
+    if (k->h_srcSizes) (void)hipHostFree(k->h_srcSizes);
+    if (k->h_srcOffsets) (void)hipHostFree(k->h_srcOffsets);
+    if (s->d_in) (void)hipFree(s->d_in);
+    if (s->d_slots) (void)hipFree(s->d_slots);
+    if (s->d_packed) (void)hipFree(s->d_packed);
+    if (s->d_sizes) (void)hipFree(s->d_sizes);
+    if (s->d_offsets) (void)hipFree(s->d_offsets);
+    if (k->d_srcSizes) (void)hipFree(k->d_srcSizes);
+    if (k->d_srcOffsets) (void)hipFree(k->d_srcOffsets);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    memset(s, 0, sizeof *s);
+    k->d_srcSizes = NULL; k->d_srcOffsets = NULL; k->h_srcSizes = NULL; k->h_srcOffsets = NULL; k->raggedCap = 0;
+}
+void lzk_combiner_quiesce(LzCtx* c)
+{
+    pthread_mutex_lock(&c->comb.mu);
+    while (c->comb.busy) pthread_cond_wait(&c->comb.cv, &c->comb.mu);
+    c->comb.busy = 1;                           /* callers queue up until lzk_combiner_resume */
+    pthread_mutex_unlock(&c->comb.mu);
+}
+void lzk_combiner_resume(LzCtx* c)
+{
+    pthread_mutex_lock(&c->comb.mu);
+    c->comb.busy = 0;
+    pthread_cond_broadcast(&c->comb.cv);
+    pthread_mutex_unlock(&c->comb.mu);
+}
+
+/* Called with comb.mu held by a caller whose job is queued and that found no batch under way: runs one batch (its own job is
+ * in it) up to the point where every member knows its result.  Returns with comb.mu held. */
+static void lead_batch(LzCtx* c, LzOneJob* mine)
+{
+    LzCombine* k = &c->comb;
+    LzOneJob* jobs[LZ_ONE_MAX_JOBS];
+    LzOneJob *j, *keepHead = NULL, *keepTail = NULL;
+    size_t inBytes = 0, maxSize = 0;
+    const int level = mine->level;
+    int n = 0, i, rc;
+    LzGuard g;
+    double t0, t1, t2, t3;
+    k->busy = 1;
+    t0 = now_s();
+    /* members: my job and every queued job of my level, in arrival order, while they fit; the others stay queued */
+    for (j = k->head; j; ) {
+        LzOneJob* const next = j->next;
+        const size_t at = (inBytes + 255) & ~(size_t)255;
+        if (j->level == level && n < LZ_ONE_MAX_JOBS && (j == mine || at + (size_t)j->srcSize <= LZ_ONE_MAX_BYTES)) {
+            j->inOff = at; inBytes = at + (size_t)j->srcSize;
+            if ((size_t)j->srcSize > maxSize) maxSize = (size_t)j->srcSize;
+            jobs[n++] = j;
+        } else {
+            j->next = NULL;
+            if (keepTail) keepTail->next = j; else keepHead = j;
+            keepTail = j;
+        }
+        j = next;
+    }
+    k->head = keepHead; k->tail = keepTail;
+    k->batches++; k->jobs += (unsigned long long)n;
+    pthread_mutex_unlock(&k->mu);
+
+    lzk_guard_acquire(&g);                      /* context lock + this device current */
+    rc = g.rc;
+    if (!rc) rc = batch_buffers(c, n, inBytes, maxSize);
+    t1 = t2 = now_s();
+    if (!rc) {
+        /* every member copies its own input in (mine: here) */
+        pthread_mutex_lock(&k->mu);
+        k->pendingIn = n - 1;
+        for (i = 0; i < n; i++) if (jobs[i] != mine) jobs[i]->state = JOB_COPY_IN;
+        pthread_cond_broadcast(&k->cv);
+        pthread_mutex_unlock(&k->mu);
+        memcpy(k->st.h_in + mine->inOff, mine->src, (size_t)mine->srcSize);
+        pthread_mutex_lock(&k->mu);
+        while (k->pendingIn) pthread_cond_wait(&k->cv, &k->mu);
+        pthread_mutex_unlock(&k->mu);
+        t2 = now_s();
+        rc = batch_on_gpu(c, jobs, n, inBytes, maxSize, level);
+        if (rc) { (void)hipStreamSynchronize(k->st.stream); (void)hipGetLastError(); }      /* nothing of this batch is left in flight */
+    }
+    if (g.c) lzk_guard_release(&g);
+    t3 = now_s();
+
+    pthread_mutex_lock(&k->mu);
+    k->tLock += t1 - t0; k->tCopyIn += t2 - t1; k->tGpu += t3 - t2; k->tBusySince = t3;
+    k->pendingOut = n;
+    for (i = 0; i < n; i++) {
+        if (rc) { jobs[i]->state = JOB_FAILED; jobs[i]->result = rc; memcpy(jobs[i]->errText, lzk_err(), LZK_ERR_BYTES); }
+        else jobs[i]->state = JOB_RESULT;
+    }
+    pthread_cond_broadcast(&k->cv);
+}
+
+int lzgpu_compress_one(const void* src, int srcSize, void* dst, int maxDstSize, int level)
+{
+    LzOneJob job;
+    LzCtx* c;
+    LzCombine* k;
+    if (srcSize < 0 || (unsigned)srcSize > (unsigned)LIZARD_MAX_INPUT_SIZE) return 0;
+    c = lzk_ctx_peek();
+    if (!c) return -LIZARDGPU_ERR_NO_DEVICE;
+    if (srcSize == 0) {                         /* reference: level byte only (lizard_compress.c:488-494) */
         if (maxDstSize < 1) return 0;
         ((uint8_t*)dst)[0] = (uint8_t)lzk_clamp_level(level);
         return 1;
     }
-    if ((rc = ensure_dev((void**)&s->d_in, &s->d_in_cap, (size_t)srcSize + 64))) return rc;
-    if ((rc = ensure_dev((void**)&s->d_slots, &s->d_slots_cap, slot))) return rc;
-    if ((rc = ensure_pinned((void**)&s->h_in, &s->h_in_cap, (size_t)srcSize))) return rc;
-    if ((rc = ensure_pinned((void**)&s->h_out, &s->h_out_cap, slot + 64))) return rc;
-    if (s->d_meta_cap < 2) {
-        LZ_HIP(hipMalloc((void**)&s->d_sizes, 2 * sizeof(uint32_t)));
-        LZ_HIP(hipMalloc((void**)&s->d_offsets, 2 * sizeof(uint64_t)));
-        s->d_meta_cap = 2;
+    k = &c->comb;
+    memset(&job, 0, sizeof job);
+    job.src = src; job.srcSize = srcSize; job.dst = dst; job.maxDst = maxDstSize; job.level = lzk_clamp_level(level);
+    pthread_mutex_lock(&k->mu);
+    if (k->tail) k->tail->next = &job; else k->head = &job;
+    k->tail = &job;
+    for (;;) {
+        if (job.state == JOB_QUEUED && !k->busy) { lead_batch(c, &job); continue; }
+        if (job.state == JOB_COPY_IN) {
+            pthread_mutex_unlock(&k->mu);
+            memcpy(k->st.h_in + job.inOff, src, (size_t)srcSize);
+            pthread_mutex_lock(&k->mu);
+            job.state = JOB_COPIED_IN;
+            if (--k->pendingIn == 0) pthread_cond_broadcast(&k->cv);
+            continue;
+        }
+        if (job.state == JOB_RESULT || job.state == JOB_FAILED) break;
+        pthread_cond_wait(&k->cv, &k->mu);
     }
-    if (s->h_meta_cap < 2) {
-        LZ_HIP(hipHostMalloc((void**)&s->h_sizes, 2 * sizeof(uint32_t), hipHostMallocDefault));
-        LZ_HIP(hipHostMalloc((void**)&s->h_offsets, 2 * sizeof(uint64_t), hipHostMallocDefault));
-        s->h_meta_cap = 2;
-    }
-    memcpy(s->h_in, src, (size_t)srcSize);
-    LZ_HIP(hipMemcpyAsync(s->d_in, s->h_in, (size_t)srcSize, hipMemcpyHostToDevice, s->stream));
-    c->hostKernelMs = -1.0f;
-    if ((rc = lzk_launch(c, s->d_in, 1, (size_t)srcSize, (size_t)srcSize, s->d_slots, slot, s->d_sizes, level, s->stream, NULL, NULL))) return rc;
-    LZ_HIP(hipMemcpyAsync(s->h_sizes, s->d_sizes, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-    LZ_HIP(hipStreamSynchronize(s->stream));
-    csize = s->h_sizes[0];
-    /* The reference's room checks compare against oend = dst + maxDstSize (lizard_compress.c:238, :489): whatever fits is
-     * written.  A ONE-byte block is the case the reference gets through by accident: Lizard_compress_generic decrements
-     * maxOutputSize after the level byte, writeBlock's raw branch tests `*op + blockSize + 4 > oend` only for the sub-block,
-     * and with maxDstSize = srcSize - 1 = 0 (the frame layer's call, lizard_frame.c:461) the unsigned room test wraps: the
-     * 6-byte block (level, 0x80, LE24 1, the byte) is emitted and its size returned.  Same here. */
-    if ((int)csize > maxDstSize && !(srcSize == 1 && maxDstSize == 0)) return 0;
-    LZ_HIP(hipMemcpyAsync(s->h_out, s->d_slots, csize, hipMemcpyDeviceToHost, s->stream));
-    LZ_HIP(hipStreamSynchronize(s->stream));
-    memcpy(dst, s->h_out, csize);
-    return (int)csize;
+    pthread_mutex_unlock(&k->mu);
+    if (job.state == JOB_RESULT) {
+        /* The reference's room checks compare against oend = dst + maxDstSize (lizard_compress.c:238, :489): whatever fits is
+         * written.  A ONE-byte block is the case the reference gets through by accident: Lizard_compress_generic decrements
+         * maxOutputSize after the level byte, writeBlock's raw branch tests `*op + blockSize + 4 > oend` only for the sub-block,
+         * and with maxDstSize = srcSize - 1 = 0 (the frame layer's call, lizard_frame.c:461) the unsigned room test wraps: the
+         * 6-byte block (level, 0x80, LE24 1, the byte) is emitted and its size returned.  Same here. */
+        if ((int)job.csize > maxDstSize && !(srcSize == 1 && maxDstSize == 0)) job.result = 0;
+        else { memcpy(dst, job.out, job.csize); job.result = (int)job.csize; }
+    } else memcpy(lzk_err(), job.errText, LZK_ERR_BYTES);
+    pthread_mutex_lock(&k->mu);                 /* the staging is free for the next batch once the last member has left */
+    if (--k->pendingOut == 0) { k->tOut += now_s() - k->tBusySince; k->busy = 0; pthread_cond_broadcast(&k->cv); }
+    pthread_mutex_unlock(&k->mu);
+    return job.result;
 }
-int lzgpu_compress_one(const void* src, int srcSize, void* dst, int maxDstSize, int level)
+
+/* where the leaders' time went, seconds since the process started: [0] waiting for the context + buffers, [1] members' copy-in,
+ * [2] GPU part (H2D, kernel, pack, D2H), [3] until the last member had copied out (tuning aid, not in the public header) */
+int LizardGPU_combinerProfile(double out[4])
 {
-    LzGuard g;
-    int rc;
-    if (srcSize < 0 || (unsigned)srcSize > (unsigned)LIZARD_MAX_INPUT_SIZE) return 0;
-    lzk_guard_acquire(&g);
-    if (g.rc) return g.rc;
-    rc = compress_one_locked(g.c, src, srcSize, dst, maxDstSize, level);
-    lzk_guard_release(&g);
-    return rc;
+    LzCtx* c = lzk_ctx_peek();
+    if (!c) return -LIZARDGPU_ERR_NO_DEVICE;
+    pthread_mutex_lock(&c->comb.mu);
+    out[0] = c->comb.tLock; out[1] = c->comb.tCopyIn; out[2] = c->comb.tGpu; out[3] = c->comb.tOut;
+    pthread_mutex_unlock(&c->comb.mu);
+    return 0;
+}
+
+/* batches launched / blocks carried by the combiner of the selected device since the process started (tests, bench) */
+int LizardGPU_combinerStats(unsigned long long* batches, unsigned long long* blocks)
+{
+    LzCtx* c = lzk_ctx_peek();
+    if (!c) return -LIZARDGPU_ERR_NO_DEVICE;
+    pthread_mutex_lock(&c->comb.mu);
+    if (batches) *batches = c->comb.batches;
+    if (blocks) *blocks = c->comb.jobs;
+    pthread_mutex_unlock(&c->comb.mu);
+    return 0;
 }
 
 /* block i is src[offsets[i] .. offsets[i+1]) (the layout of LizardGPU_compressBlocks_host_packed); synchronous */

@@ -28,6 +28,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;       // optional
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -63,6 +64,7 @@ int rccl_load()
     LZ_SYM(CommDestroy, "ncclCommDestroy"); LZ_SYM(AllGather, "ncclAllGather"); LZ_SYM(Broadcast, "ncclBroadcast");
     LZ_SYM(GroupStart, "ncclGroupStart"); LZ_SYM(GroupEnd, "ncclGroupEnd"); LZ_SYM(GetErrorString, "ncclGetErrorString");
 #undef LZ_SYM
+    *(void**)(&g_rccl.CommAbort) = dlsym(so, "ncclCommAbort");
     g_rccl.so = so; g_rccl.shared = shared;
     return 0;
 }
@@ -112,6 +114,15 @@ int select_shard_device(int rank)
     return 0;
 }
 
+// A collective failed inside a group: part of the ranks have posted, the others never will.  Synchronising their streams could
+// wait for ever; the communicators are destroyed instead (the next call makes new ones).  RCCL only; called with g_rccl_mu held.
+void abort_all_comms()
+{
+    if (!g_rccl.so) return;
+    for (int i = 0; i < g_allCount; i++) if (g_allComms[i]) { if (g_rccl.CommAbort) (void)g_rccl.CommAbort(g_allComms[i]); else (void)g_rccl.CommDestroy(g_allComms[i]); g_allComms[i] = nullptr; }
+    g_allCount = 0;
+}
+
 void lz_shard_shutdown()
 {
     pthread_mutex_lock(&g_rccl_mu);
@@ -139,6 +150,11 @@ void LizardGPU_offsetsFromSizes(const uint32_t* sizes, size_t nBlocks, uint64_t*
 
 int LizardGPU_setCollectives(const LizardGPU_Collectives* table)
 {
+    t_err[0] = 0;
+    if (table && (!table->allGather || !table->broadcast || !table->groupStart || !table->groupEnd)) {
+        snprintf(t_err, sizeof t_err, "LizardGPU_setCollectives: every member of the table must be set");
+        return -LIZARDGPU_ERR_ARG;
+    }
     pthread_mutex_lock(&g_rccl_mu);
     g_haveUserCol = table != nullptr;
     if (table) { g_userCol.allGather = table->allGather; g_userCol.broadcast = table->broadcast; g_userCol.groupStart = table->groupStart; g_userCol.groupEnd = table->groupEnd; }
@@ -180,6 +196,7 @@ int LizardGPU_compressBlocks_sharded(int nDevices, const int* devices, const voi
     const int savedSel = t_device;
     hipStream_t streams[LZ_MAX_DEVICES] = {};
     int nLaunched = 0;                                          // ranks whose stream carries work of this call
+    bool exchangeFailed = false;                                // a collective failed inside the group: the streams are not synchronised
     // 1. every device compresses its contiguous range; its sizes land in place inside its copy of the all-sizes array
     for (int r = 0; r < nDevices && !rc; r++) {
         size_t first, count;
@@ -199,10 +216,16 @@ int LizardGPU_compressBlocks_sharded(int nDevices, const int* devices, const voi
         void* comms[LZ_MAX_DEVICES]; void* strs[LZ_MAX_DEVICES];
         for (int r = 0; r < nDevices; r++) { comms[r] = g_haveUserCol ? (void*)(intptr_t)r : (void*)g_allComms[r]; strs[r] = (void*)streams[r]; }
         t_shardDevs = devs;
-        rc = lz_exchange_all(collectives(), kHipOps, nDevices, comms, nBlocks, d_allSizes, d_offsets, strs, select_shard_device);
+        // everything that can fail without the transport is checked BEFORE the group opens: a group that is closed with only
+        // some of its ranks posted can hang in ncclGroupEnd or in the synchronise below
+        for (int r = 0; r < nDevices && !rc; r++) rc = select_shard_device(r);
+        if (!rc) {
+            rc = lz_exchange_all(collectives(), kHipOps, nDevices, comms, nBlocks, d_allSizes, d_offsets, strs, select_shard_device);
+            if (rc && !g_haveUserCol) { exchangeFailed = true; abort_all_comms(); }
+        }
         t_shardDevs = nullptr;
     }
-    for (int r = 0; r < nLaunched; r++) {
+    for (int r = 0; r < nLaunched && !exchangeFailed; r++) {
         if (hipSetDevice(devs[r]) == hipSuccess && hipStreamSynchronize(streams[r]) != hipSuccess && !rc) {
             snprintf(t_err, sizeof t_err, "device %d: stream synchronise failed", devs[r]); rc = -LIZARDGPU_ERR_HIP;
         }
@@ -223,20 +246,28 @@ int LizardGPU_commUniqueId(void* id128)
     return rc;
 }
 
+// Lock order of this file: g_rccl_mu first, then a device context (Guard) — as LizardGPU_compressBlocks_sharded does.
 int LizardGPU_commInitRank(const void* id128, int nRanks, int rank)
 {
-    Guard g;                                                    // the communicator lives on the selected device
-    if (g.rc) return g.rc;
+    t_err[0] = 0;
     if (!id128 || nRanks < 1 || rank < 0 || rank >= nRanks) { snprintf(t_err, sizeof t_err, "bad argument"); return -LIZARDGPU_ERR_ARG; }
     pthread_mutex_lock(&g_rccl_mu);
-    int rc = rccl_load();
-    if (!rc) {
-        if (g_rankComm) { (void)g_rccl.CommDestroy(g_rankComm); g_rankComm = nullptr; }
-        ncclUniqueId id;
-        memcpy(&id, id128, sizeof id);
-        const ncclResult_t r_ = g_rccl.CommInitRank(&g_rankComm, nRanks, id, rank);
-        if (r_ != ncclSuccess) { g_rankComm = nullptr; rc = nccl_fail("ncclCommInitRank", r_); }
-        else { g_rankCount = nRanks; g_rankIndex = rank; }
+    int rc;
+    {
+        Guard g;                                                // the communicator lives on the selected device
+        rc = g.rc;
+        if (!rc && g_haveUserCol) {
+            // a transport installed with LizardGPU_setCollectives needs no RCCL communicator: the rank index is what it is handed as `comm`
+            if (g_rankComm && g_rccl.so) (void)g_rccl.CommDestroy(g_rankComm);
+            g_rankComm = nullptr; g_rankCount = nRanks; g_rankIndex = rank;
+        } else if (!rc && !(rc = rccl_load())) {
+            if (g_rankComm) { (void)g_rccl.CommDestroy(g_rankComm); g_rankComm = nullptr; }
+            ncclUniqueId id;
+            memcpy(&id, id128, sizeof id);
+            const ncclResult_t r_ = g_rccl.CommInitRank(&g_rankComm, nRanks, id, rank);
+            if (r_ != ncclSuccess) { g_rankComm = nullptr; g_rankCount = 0; g_rankIndex = -1; rc = nccl_fail("ncclCommInitRank", r_); }
+            else { g_rankCount = nRanks; g_rankIndex = rank; }
+        }
     }
     pthread_mutex_unlock(&g_rccl_mu);
     return rc;
@@ -244,15 +275,19 @@ int LizardGPU_commInitRank(const void* id128, int nRanks, int rank)
 
 int LizardGPU_gatherSizes_device(const uint32_t* d_localSizes, size_t nBlocks, uint32_t* d_allSizes, uint64_t* d_offsets, void* stream)
 {
-    Guard g;
-    if (g.rc) return g.rc;
     pthread_mutex_lock(&g_rccl_mu);
-    int rc = 0;
-    if (!g_rankComm) { snprintf(t_err, sizeof t_err, "LizardGPU_commInitRank has not been called"); rc = -LIZARDGPU_ERR_ARG; }
-    else if (!d_localSizes || !d_allSizes || !d_offsets || nBlocks < (size_t)g_rankCount || nBlocks > 0xFFFFFFFFu) {
-        snprintf(t_err, sizeof t_err, "bad argument"); rc = -LIZARDGPU_ERR_ARG;
+    int rc;
+    {
+        Guard g;
+        rc = g.rc;
+        if (rc) {}
+        else if (g_rankIndex < 0 || (!g_rankComm && !g_haveUserCol)) { snprintf(t_err, sizeof t_err, "LizardGPU_commInitRank has not been called"); rc = -LIZARDGPU_ERR_ARG; }
+        else if (!d_localSizes || !d_allSizes || !d_offsets || nBlocks < (size_t)g_rankCount || nBlocks > 0xFFFFFFFFu) {
+            snprintf(t_err, sizeof t_err, "bad argument"); rc = -LIZARDGPU_ERR_ARG;
+        }
+        else rc = lz_gather_sizes(collectives(), kHipOps, g_haveUserCol ? (void*)(intptr_t)g_rankIndex : (void*)g_rankComm, g_rankIndex, g_rankCount,
+                                  d_localSizes, nBlocks, d_allSizes, d_offsets, stream);
     }
-    else rc = lz_gather_sizes(collectives(), kHipOps, (void*)g_rankComm, g_rankIndex, g_rankCount, d_localSizes, nBlocks, d_allSizes, d_offsets, stream);
     pthread_mutex_unlock(&g_rccl_mu);
     return rc;
 }

@@ -25,6 +25,12 @@ struct LzBatch {
                     // levels 11/31/22/42 LZ_TABWIDE_BYTES(18), hashChain levels LZ_HC_SLOT_BYTES(maxBlock)
     u64 tableStride;
     u32 tableSlots;  // number of table slots behind `tables` (hashChain with large blocks: fewer than resident waves; the waves without one leave)
+    const u32* srcSizes;  // nullptr: every block is blockSize bytes except the last (lastBlockSize); else block b is srcSizes[b] bytes (<= blockSize,
+                          // >= 1): the ragged batches of the one-block entry points' combiner (lizard_pipeline_host.c)
+    const u64* srcOffsets; // nullptr: block b starts at src + b * blockSize; else at src + srcOffsets[b] (ragged batches, packed back to back)
+    u32 activeWaves; // block-claiming waves per workgroup (<= the kernel's waves / producers).  A launch smaller than the machine spreads
+                     // its blocks over all CUs — ceil(nBlocks / grid) claiming waves each — instead of filling a few CUs with 13-16 waves:
+                     // a wave with the CU's LDS pipe, L1 and issue slots nearly to itself parses ~1.5x faster
 };
 
 // Residency by construction.  LDS is what limits the number of tables in flight, and the hardware hands it out
@@ -58,6 +64,9 @@ struct LzBatch {
 #define LZ_WAVES_FASTLDS_HUF  11
 #ifndef LZ_WIDE_OCC
 #define LZ_WIDE_OCC 1                        // occupancy summaries of the 2^18-slot global tables (levels 11/31, 22/42)
+#endif
+#ifndef LZ_SPREAD_SMALL
+#define LZ_SPREAD_SMALL 1                    // launches smaller than the machine: one claiming wave per CU before a second one anywhere (lizard_gpu.hip launch())
 #endif
 #ifndef LZ_MAX_WAVES
 #define LZ_MAX_WAVES          16             // scratch / table slots per CU
@@ -97,6 +106,7 @@ __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
     // table slots are dealt out wave-index-major, so that a launch with fewer slots than waves keeps every CU busy
     const u64 tslot = (u64)wave * gridDim.x + blockIdx.x;
     if (tslot >= a.tableSlots) return;
+    if (wave >= a.activeWaves) return;
     void* tableMem;
     if constexpr (NLDS == W)      tableMem = (void*)ldsTables[wave];
     else if constexpr (NLDS == 0) tableMem = (void*)(a.tables + tslot * a.tableStride);
@@ -110,8 +120,9 @@ __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
         lz_converge();
         const u32 b = lz_claim_index(a.counter);
         if (b >= a.nBlocks) break;
-        const u32 n = (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
-        const u32 c = lz_compress_block<PARSER, HASHLOG, AUX, HUF>(a.src + (u64)b * a.blockSize, n, a.dst + (u64)b * a.dstStride,
+        const u32 n = a.srcSizes ? lz_uniform(a.srcSizes[b]) : (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
+        const u8* const srcb = a.src + (a.srcOffsets ? lz_uniform64(a.srcOffsets[b]) : (u64)b * a.blockSize);
+        const u32 c = lz_compress_block<PARSER, HASHLOG, AUX, HUF>(srcb, n, a.dst + (u64)b * a.dstStride,
                                                                   a.level, tableMem, ws, scratch, my.ring, tabKind,
                                                                   POOL ? &hufPool[0][0] : nullptr, POOL ? &hufPoolMask : nullptr, (u32)POOL,
                                                                   &hcPool, (u32)a.blockSize, OCCLOG ? wideOcc[OCCLOG ? wave : 0] : nullptr, (u32)OCCLOG, (u32)WIDETAGLOG);
@@ -181,6 +192,7 @@ __global__ __launch_bounds__(64 * (HUF ? LZ_SPLIT_PROD_HUF + LZ_SPLIT_CONS_HUF :
     s.src = a.src; s.blockSize = a.blockSize; s.nBlocks = a.nBlocks; s.lastBlockSize = a.lastBlockSize;
     s.dst = a.dst; s.dstStride = a.dstStride; s.sizes = a.sizes; s.level = a.level; s.counter = a.counter;
     s.arena = a.scratch + (u64)blockIdx.x * LZ_MAX_WAVES * LZ_SCRATCH_BYTES; s.nProd = NP; s.nCons = NC; s.nBufs = NB; s.qn = QN;
+    s.srcSizes = a.srcSizes; s.srcOffsets = a.srcOffsets; s.activeProd = a.activeWaves < NP ? a.activeWaves : NP;
     if (wave < NP) lz_split_producer<12>(s, sh, wave, (void*)tables[wave < NP ? wave : 0], rings[wave < NP ? wave : 0]);
     else           lz_split_consumer<HUF>(s, sh, wave - NP, hufWs[HUF ? wave - NP : 0]);
 }

@@ -61,6 +61,9 @@ struct LzSplitArgs {
     u8* arena;                                               // this workgroup's scratch: producers' buffers, then consumers' staging
     u32 nProd, nCons;
     u32 nBufs, qn;                                           // sequence buffers per producer; mailbox words per consumer
+    const u32* srcSizes;                                     // per-block input sizes of a ragged batch, or nullptr (LzBatch::srcSizes)
+    const u64* srcOffsets;                                   // per-block input offsets of a ragged batch, or nullptr (LzBatch::srcOffsets)
+    u32 activeProd;                                          // producers that claim blocks (LzBatch::activeWaves); the others leave at once
 };
 LZ_DEV u8* lz_split_buf(const LzSplitArgs& a, u32 bufIndex) { return a.arena + (u64)bufIndex * LZ_SPLIT_BUF_BYTES; }
 #define LZ_SPLIT_CONS_BYTES (2u * LZ_SUBBLOCK_PAD + LZ_SPLIT_OPS_BYTES)
@@ -81,10 +84,11 @@ LZ_DEV void lz_split_producer(const LzSplitArgs& a, const LzSplitShared& sh, u32
     const LzTab tab = lz_tab_bind<HASHLOG>(tableMem);
     for (;;) {
         lz_converge();
+        if (prod >= a.activeProd) break;                                         // a small launch: this producer's blocks went to other CUs
         const u32 b = lz_claim_index(a.counter);
         if (b >= a.nBlocks) break;
-        const u32 n = (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
-        const u8* src = a.src + (u64)b * a.blockSize;
+        const u32 n = a.srcSizes ? lz_uniform(a.srcSizes[b]) : (b == a.nBlocks - 1u) ? a.lastBlockSize : (u32)a.blockSize;
+        const u8* src = a.src + (a.srcOffsets ? lz_uniform64(a.srcOffsets[b]) : (u64)b * a.blockSize);
         const u32 cons = lz_lds_claim(sh.nextCons) % a.nCons;                  // the block's consumer
         lz_tab_fresh<HASHLOG>(tab); st.sweepAt = LzTab::kSweepEvery;
         lz_lds_sync();
@@ -160,7 +164,7 @@ LZ_DEV void lz_split_consumer(const LzSplitArgs& a, const LzSplitShared& sh, u32
         st.seq = (u64*)(buf + LZ_SPLIT_HDR);
         st.nseq = lz_readlane(hv, LZJ_NSEQ); st.nlit = lz_readlane(hv, LZJ_NLIT); st.nflags = lz_readlane(hv, LZJ_NFLAGS);
         st.lastLits = lz_readlane(hv, LZJ_LASTLITS); st.noff16 = st.noff24 = 0;
-        const u8* src = a.src + (u64)b * a.blockSize;
+        const u8* src = a.src + (a.srcOffsets ? lz_uniform64(a.srcOffsets[b]) : (u64)b * a.blockSize);
         u8* dst = a.dst + (u64)b * a.dstStride;
         // where this sub-block starts in dst: 1 (behind the level byte, lizard_compress.c:488) or where the block's previous
         // sub-block — handled by this consumer, from this producer — ended: kept in a word of this consumer's own scratch

@@ -39,6 +39,7 @@ LZ_DEV u64 lz_readlane64(u64 v, u32 src) { return (u64)lz_readlane((u32)v, src) 
 
 // value held by the first active lane, as a scalar.  Used to pin wave-uniform state into SGPRs.
 LZ_DEV u32 lz_uniform(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+LZ_DEV u64 lz_uniform64(u64 v) { return (u64)lz_uniform((u32)v) | ((u64)lz_uniform((u32)(v >> 32)) << 32); }
 
 // `v` with lane `dst` (wave-uniform) replaced by the wave-uniform value x.  Together with lz_readlane this makes a VGPR
 // a 64-entry table that wave-uniform (scalar) code reads and writes without touching memory.  (Compare + select: two

@@ -196,13 +196,22 @@ void entry_split(void* p)
 }
 }  // namespace
 
+// srcSizes / activeProd: the ragged batches and the producer cap of small launches (LzBatch::srcSizes, ::activeWaves); nullptr / 0 = off
+extern "C" int emul_compress_split_ragged(const void* src, int nBlocks, int blockSize, int lastBlockSize, const unsigned* srcSizes, void* dst,
+                                          int dstStride, unsigned* sizes, int level, int nProd, int nCons, int activeProd, unsigned seed);
 extern "C" int emul_compress_split(const void* src, int nBlocks, int blockSize, int lastBlockSize, void* dst, int dstStride,
                                    unsigned* sizes, int level, int nProd, int nCons, unsigned seed)
+{
+    return emul_compress_split_ragged(src, nBlocks, blockSize, lastBlockSize, nullptr, dst, dstStride, sizes, level, nProd, nCons, 0, seed);
+}
+extern "C" int emul_compress_split_ragged(const void* src, int nBlocks, int blockSize, int lastBlockSize, const unsigned* srcSizes, void* dst,
+                                          int dstStride, unsigned* sizes, int level, int nProd, int nCons, int activeProd, unsigned seed)
 {
     const u32 nBufs = 2u + (seed & 1u), qn = 64u;              // odd seeds: three buffers per producer
     if ((level != 10 && level != 30) || nProd < 1 || nCons < 1 || (u32)nProd * nBufs > qn) return -1;
     LzSplitArgs a;
     a.src = (const u8*)src; a.blockSize = (u64)blockSize; a.nBlocks = (u32)nBlocks; a.lastBlockSize = (u32)lastBlockSize;
+    a.srcSizes = srcSizes; a.activeProd = activeProd > 0 ? (u32)activeProd : 0xFFFFFFFFu;
     a.dst = (u8*)dst; a.dstStride = (u64)dstStride; a.sizes = sizes; a.level = (u32)level;
     u32 counter = 0; a.counter = &counter;
     const size_t arenaBytes = LZ_SPLIT_ARENA_BYTES((size_t)nProd, (size_t)nCons, nBufs);

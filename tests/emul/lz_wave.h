@@ -99,6 +99,8 @@ LZ_DEV u32 lz_uniform(u32 v)
     return (u32)w->res[me];
 }
 
+LZ_DEV u64 lz_uniform64(u64 v) { return (u64)lz_uniform((u32)v) | ((u64)lz_uniform((u32)(v >> 32)) << 32); }
+
 // x and dst are wave-uniform; no other lane's state is needed to emulate v_writelane
 LZ_DEV u32 lz_writelane(u32 v, u32 x, u32 dst) { return lz_lane() == dst ? x : v; }
 

@@ -206,7 +206,8 @@ def test_reference_test_programs_on_the_gpu_library(prog, args, tmp_path):
     ldd = subprocess.check_output(["ldd", exe]).decode()
     assert "liblizard_amd.so" in ldd and "liblizard_ref" not in ldd
     undefined = subprocess.check_output(["nm", "-u", exe]).decode()
-    assert "Lizard_decompress_safe" in undefined and ("LizardF_decompress" in undefined or prog == "fuzzer_amd")   # decoder and frames come from the product
+    assert {"fuzzer_amd": "Lizard_decompress_safe_continue", "frametest_amd": "LizardF_decompress",
+            "fullbench_amd": "Lizard_decompress_safe_forceExtDict"}[prog] in undefined        # decoder and frames come from the product
     if prog == "fullbench_amd":
         f = tmp_path / "in.bin"
         f.write_bytes(util.datagen(3 << 20, 0.5, 0.0, 3))

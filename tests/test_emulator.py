@@ -3,6 +3,7 @@ SIMT emulator (tests/emul) and checks them bit-exact against the oracle and the 
 This is how kernel logic is debugged without a GPU; the GPU parity tests (-m gpu) repeat the same
 comparisons through the C ABI on real hardware."""
 import ctypes
+import random
 import json
 import os
 
@@ -185,6 +186,30 @@ def test_emulated_split_producers_and_consumers(level):
         outs = emul_split(part, bs, level, nprod, ncons, seed=bs + nprod)
         for i, o in enumerate(outs):
             assert o == util.oracle_compress(part[i * bs:(i + 1) * bs], level), (level, bs, nprod, ncons, i)
+
+
+@pytest.mark.parametrize("level", [10, 30])
+def test_emulated_split_ragged_batch_with_producer_cap(level):
+    """The batches the one-block entry points' combiner launches (lizard_amd/csrc/lizard_pipeline_host.c): blocks of DIFFERENT
+    sizes at a common stride (LzBatch::srcSizes) and fewer claiming producers than the workgroup has (LzBatch::activeWaves)."""
+    emu = util.emulator()
+    emu.emul_compress_split_ragged.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint]
+    rnd = random.Random(level)
+    lens = [1, 19, 20, 21, 300000, 131072, 131073, 5, 262144, 70000, 100, 262143, 40, 131071, 200000, 64]
+    stride = 300032
+    blocks = [util.datagen(n, rnd.choice((0.2, 0.5, 0.9)), 0.0, n + level) for n in lens]
+    src = ctypes.create_string_buffer(stride * len(lens))
+    for i, b in enumerate(blocks):
+        ctypes.memmove(ctypes.addressof(src) + i * stride, b, len(b))
+    sizes_in = (ctypes.c_uint * len(lens))(*lens)
+    dstride = util.oracle().lzo_compress_bound(stride) + 64
+    for nprod, ncons, active, seed in ((4, 2, 1, 1), (5, 3, 2, 2), (3, 1, 3, 3), (13, 3, 1, 4) if level == 10 else (10, 6, 2, 4)):
+        dst = ctypes.create_string_buffer(len(lens) * dstride)
+        sizes = (ctypes.c_uint * len(lens))()
+        assert emu.emul_compress_split_ragged(src, len(lens), stride, stride, sizes_in, dst, dstride, sizes, level, nprod, ncons, active, seed) == 0
+        for i, b in enumerate(blocks):
+            assert dst.raw[i * dstride:i * dstride + sizes[i]] == util.oracle_compress(b, level), (level, nprod, ncons, active, i, len(b))
 
 
 def _beyond_width_case(gap, seed):
