@@ -1,0 +1,51 @@
+"""GPU: the N > 1 branch of bench.py executed for real on a one-GPU box: two torchrun ranks share the
+device; torch.distributed runs on gloo and the library's size exchange (LizardGPU_commInitRank + LizardGPU_gatherSizes_device)
+goes through a host-bounce transport installed with LizardGPU_setCollectives.  Same bench code path as an RCCL job: per-rank
+kernel / gather timings, rank 0's cpu_baseline, every rank verifying every block of its shard."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+import util
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,blocks", [(2, 1024), (3, 683)])
+def test_bench_two_and_three_ranks_on_one_device(world, blocks):
+    import torch
+    if torch.cuda.device_count() >= world:
+        extra = ["--transport", "host-bounce"]               # (a box with enough devices: still exercise the bounce transport here)
+    else:
+        extra = []
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(util.ROOT, "bench.py"), "--gpus", str(world), "--headline-only",
+           "--blocks", str(blocks), "--steps", "2", "--warmup", "1", "--cpu-seconds", "1", "--cpu-all-seconds", "0"] + extra
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=util.ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and out["steps"] == 2 and out["warmup"] == 1
+    assert out["config"]["blocks_per_gpu"] == blocks
+    assert "host bounce" in out["config"]["size_gather"] and "LizardGPU_setCollectives" in out["config"]["size_gather"]
+    assert [p["rank"] for p in out["per_rank"]] == list(range(world))
+    assert all(p["kernel_ms"] > 0 and p["gather_us"] > 0 for p in out["per_rank"])
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["cores"] == 1
+    assert out["blocks_checked"] == world * blocks and out["blocks_checked_bytes"] == world * blocks
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0
+    # the whole job's compressed size: every rank's blocks are different blocks (seed = rank * blocks + b)
+    want = sum(len(util.oracle_compress(util.datagen(262144, 0.5, 0.0, b), 10)) for b in (0, blocks, world * blocks - 1))
+    assert want > 0 and out["compressed_bytes"] > world * blocks * 100000
