@@ -18,33 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, ROOT)
 import util                                              # noqa: E402
 from test_emulator import emul_compress                  # noqa: E402
-from test_random_parity import LEVELS, make_case         # noqa: E402
-
-
-def make_long_case(rng, max_size):
-    target = rng.randrange(max_size // 4, max_size)
-    out = bytearray()
-    while len(out) < target:
-        kind = rng.randrange(6)
-        n = rng.choice([rng.randrange(20000, 70000), rng.randrange(60000, 140000), rng.randrange(130000, 200000), rng.randrange(1, 3000)])
-        if kind == 0:
-            seg = bytes([rng.randrange(256)]) * n
-        elif kind == 1:
-            per = rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 63, 64, 65, 255, 300, 4096, 32768, 65535, 65536, 65537])
-            pat = rng.randbytes(per)
-            seg = (pat * (n // per + 1))[:n]
-        elif kind == 2 and len(out) > 16:
-            dist = min(rng.choice([8, 9, 16, 4096, 32768, 65527, 65535, 65536, 65537, 131072, 131080, len(out)]), len(out))
-            start = len(out) - dist
-            seg = bytes(out[start:start + min(n, dist)])
-        elif kind == 3:
-            seg = util.datagen(min(n, 60000), rng.choice([0.1, 0.5, 0.9, 1.0]), 0.0, rng.randrange(1 << 30))
-        elif kind == 4:
-            seg = rng.randbytes(rng.randrange(1, 40000))
-        else:
-            seg = b"".join(bytes([rng.randrange(1, 255)]) + b"\0\0\0\0" + bytes([rng.randrange(256)]) + rng.randbytes(rng.randrange(0, 12)) for _ in range(rng.randrange(1, 200)))
-        out += seg
-    return bytes(out[:target])
+from test_random_parity import LEVELS, make_case, make_long_case         # noqa: E402
 
 
 def main():

@@ -98,6 +98,38 @@ def test_blocks_above_4mib(L):
     assert L.LizardGPU_maxBlockSize(11) == L.LizardGPU_maxBlockSize(10) == L.LizardGPU_maxBlockSize(42) == L.LizardGPU_maxBlockSize(13) == 0x7E000000
 
 
+def test_sweeps_due_inside_long_matches(L):
+    """The shape of the round-3 soak finding at EVERY modular-position table, on the GPU: long matches (a run, a periodic stretch:
+    one match per sub-block) carry the position across the table's sweep points, and what follows probes slots whose entries are
+    one position width + 100 old — 100 modulo the width — with the same bytes and the same check bits.  Levels 10/30: 2^17,
+    sweep every 2^15 (the original bug); 11/31: 2^22, sweep every 2^20; 21/41/22/42: 2^24, sweep every 2^22."""
+    import random
+    rnd = random.Random(17)
+
+    def case(width, filler):
+        x = util.datagen(600000 if width > (1 << 17) else 50000, 0.5, 0.0, 5)
+        gap = width + 100 - len(x)
+        if filler == "run":
+            mid = bytes(gap)
+        else:                                                   # period below the 64 KiB window: one long match per sub-block
+            pat = rnd.randbytes(filler)
+            mid = (pat * (gap // filler + 1))[:gap]
+        return x + mid + x + util.datagen(200000, 0.4, 0.0, 6)
+
+    for width, levels in ((1 << 17, (10, 30)), (1 << 22, (11, 31, 10))):
+        for filler in ("run", 40000, 65535):
+            data = case(width, filler)
+            for level in levels:
+                out, r = gpu_compress(L, data, level)
+                assert out == util.oracle_compress(data, level), (width, filler, level)
+    # priceFast: offsets up to 4 MiB — a 3 MiB pattern repeated (every sub-block one off24 match across the sweeps at 2^22, 2^23, ...)
+    pat = rnd.randbytes(3 << 20)
+    data = pat * 6 + util.datagen(100000, 0.5, 0.0, 7)                       # 18.1 MiB: beyond 2^24 positions
+    for level in (21, 42):
+        out, r = gpu_compress(L, data, level)
+        assert out == util.oracle_compress(data, level), ("3 MiB period", level)
+
+
 def test_frame_style_capacity(L):
     """maxDstSize = srcSize-1 (reference lib/lizard_frame.c:461): identical bytes when it fits, 0 when not."""
     for level in [l for l in (10, 21, 30) if L.LizardGPU_levelSupported(l)]:
