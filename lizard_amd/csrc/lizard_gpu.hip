@@ -238,11 +238,20 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
             LZ_HIP(hipMemGetInfo(&freeB, &totalB));
             size_t budget = freeB / 2u;
             if (budget > ((size_t)128 << 30)) budget = (size_t)128 << 30;
+            // LIZARDGPU_HC_WORKAREA_MB caps the reservation (a caller that shares the device with other allocations); fewer work
+            // areas than resident waves only means fewer hashChain blocks in flight (the waves without one leave)
+            if (const char* e = getenv("LIZARDGPU_HC_WORKAREA_MB")) {
+                const size_t mb = (size_t)strtoull(e, nullptr, 10);
+                if (mb > 0 && (mb << 20) < budget) budget = mb << 20;
+            }
             size_t nSlots = budget / LZ_HC_SLOT_BYTES(cap);
             if (nSlots > (size_t)c.cus * LZ_MAX_WAVES) nSlots = (size_t)c.cus * LZ_MAX_WAVES;
             if (nSlots == 0) { snprintf(t_err, sizeof t_err, "level %d: no room for a hashChain work area of %zu bytes", lv, (size_t)LZ_HC_SLOT_BYTES(cap)); return -LIZARDGPU_ERR_NOMEM; }
             LZ_HIP(hipMalloc((void**)&c.hcSlots, nSlots * LZ_HC_SLOT_BYTES(cap)));
             c.hcMaxBlock = cap; c.hcNSlots = nSlots;
+            if (getenv("LIZARDGPU_VERBOSE"))
+                fprintf(stderr, "liblizard_amd: device %d: hashChain levels reserve %zu work areas of %zu bytes (%.1f GiB of %.1f GiB free; LIZARDGPU_HC_WORKAREA_MB caps it)\n",
+                        c.device, nSlots, (size_t)LZ_HC_SLOT_BYTES(cap), (double)(nSlots * LZ_HC_SLOT_BYTES(cap)) / (double)(1u << 30), (double)freeB / (double)(1u << 30));
         }
         a.tables = c.hcSlots; a.tableStride = LZ_HC_SLOT_BYTES(c.hcMaxBlock); a.tableSlots = (u32)c.hcNSlots;
     } else if (lv == 11 || lv == 31 || lv == 22 || lv == 42) {
@@ -271,14 +280,17 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
     if (k0) LZ_HIP(hipEventRecord(k0, stream));
     const dim3 g(grid), t(64 * W);
     switch (lv) {
-    case 10: if (LZ_FAST12_SPLIT) hipLaunchKernelGGL(lz_fast12_split_kernel<false>, g, t, 0, stream, a);
-             else if (fastMixed) hipLaunchKernelGGL((lz_fast12_kernel<false, true>), g, t, 0, stream, a);
+#if LZ_FAST12_SPLIT
+    case 10: hipLaunchKernelGGL(lz_fast12_split_kernel<false>, g, t, 0, stream, a); break;
+    case 30: hipLaunchKernelGGL(lz_fast12_split_kernel<true>, g, t, 0, stream, a); break;
+#else
+    case 10: if (fastMixed) hipLaunchKernelGGL((lz_fast12_kernel<false, true>), g, t, 0, stream, a);
              else           hipLaunchKernelGGL((lz_fast12_kernel<false, false>), g, t, 0, stream, a);
              break;
-    case 30: if (LZ_FAST12_SPLIT) hipLaunchKernelGGL(lz_fast12_split_kernel<true>, g, t, 0, stream, a);
-             else if (fastMixed) hipLaunchKernelGGL((lz_fast12_kernel<true, true>), g, t, 0, stream, a);
+    case 30: if (fastMixed) hipLaunchKernelGGL((lz_fast12_kernel<true, true>), g, t, 0, stream, a);
              else           hipLaunchKernelGGL((lz_fast12_kernel<true, false>), g, t, 0, stream, a);
              break;
+#endif
     case 11: hipLaunchKernelGGL(lz_fast18_kernel<false>, g, t, 0, stream, a); break;
     case 31: hipLaunchKernelGGL(lz_fast18_kernel<true>, g, t, 0, stream, a); break;
     case 13: case 14: case 15: hipLaunchKernelGGL((lz_hashchain_kernel<false, 5>), g, t, 0, stream, a); break;
@@ -298,6 +310,7 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
     LZ_HIP(hipEventRecord(c.ev1, stream));
     if (k1) LZ_HIP(hipEventRecord(k1, stream));
     c.timed = true;
+    c.lastSplit = LZ_FAST12_SPLIT && (lv == 10 || lv == 30);
     return 0;
 }
 
@@ -455,9 +468,14 @@ int LizardGPU_profileDump(unsigned long long out[16])
     (void)hipDeviceSynchronize();
     for (int w = 0; w < c.cus * LZ_MAX_WAVES; w++) {
         unsigned long long v[16];
-        if (hipMemcpy(v, c.scratch + (size_t)(w + 1) * LZ_SCRATCH_BYTES - 128, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -LIZARDGPU_ERR_HIP;
+        // the one-wave-per-block kernels keep a wave's record at the tail of its scratch slot; the producer / consumer kernels of
+        // levels 10 / 30 (whose sequence buffers cover those tails) at the end of the workgroup's arena
+        const size_t group = (size_t)(w / LZ_MAX_WAVES) * LZ_MAX_WAVES * LZ_SCRATCH_BYTES;
+        u8* at = c.lastSplit ? c.scratch + group + (size_t)LZ_MAX_WAVES * LZ_SCRATCH_BYTES - (size_t)(w % LZ_MAX_WAVES + 1) * 128
+                             : c.scratch + (size_t)(w + 1) * LZ_SCRATCH_BYTES - 128;
+        if (hipMemcpy(v, at, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -LIZARDGPU_ERR_HIP;
         for (int k = 0; k < 15; k++) out[k] += v[k];
-        (void)hipMemset(c.scratch + (size_t)(w + 1) * LZ_SCRATCH_BYTES - 128, 0, sizeof v);
+        (void)hipMemset(at, 0, sizeof v);
     }
     return 0;
 }

@@ -55,6 +55,7 @@ typedef struct LzCtx {
     uint32_t* counter;
     hipEvent_t ev0, ev1;
     int   timed;
+    int   lastSplit;            /* the last compress launch was the producer / consumer form (profile builds: where the records are) */
     int   laneOrderOk;          /* self-check at context creation: lanes of one DS atomic are served in lane order */
     float hostKernelMs;         /* sum over the chunks of the last host-buffer call (< 0: last call was a device call) */
     LzStage stage[LZ_STAGES];

@@ -124,8 +124,12 @@ int Lizard_saveDict(Lizard_stream_t* streamPtr, char* safeBuffer, int dictSize)
 
 int Lizard_compress_continue(Lizard_stream_t* streamPtr, const char* src, char* dst, int srcSize, int maxDstSize)
 {
+    static int noted = 0;
     int r;
     if (!streamPtr) return 0;
+    if (!__atomic_exchange_n(&noted, 1, __ATOMIC_RELAXED) && getenv("LIZARDGPU_VERBOSE"))      /* said once, for those who ask */
+        fprintf(stderr, "liblizard_amd: Lizard_compress_continue compresses every block WITHOUT its history (valid, decodable linked-mode "
+                        "blocks; not the reference's linked-mode bytes — include/lizard_amd.h)\n");
     if (srcSize > 0) {   /* the reference moves `end` before it compresses (lizard_compress.c:491), so a failed call counts too;
                             :560-561: contiguous input extends the prefix, anything else starts a new one */
         streamPtr->prefix = (src == streamPtr->end ? streamPtr->prefix : 0) + (size_t)srcSize;

@@ -131,8 +131,12 @@ __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
     }
 }
 
+#ifndef LZ_FAST12_SPLIT
+#define LZ_FAST12_SPLIT 1
+#endif
+#if !LZ_FAST12_SPLIT
 // levels 10 / 30, the one-wave-per-block form of rounds 1-2 (launched only by LZ_FAST12_SPLIT=0 builds, kept for side-by-side
-// measurements; the library runs lz_fast12_split_kernel below): fastSmall parser, 2^12-slot table + sequence ring (+ Huffman
+// measurements — compiled into -DLZ_FAST12_SPLIT=0 variant builds only; the library runs lz_fast12_split_kernel below): fastSmall parser, 2^12-slot table + sequence ring (+ Huffman
 // workspace).  MIXED: level 10 thirteen waves with the 12 KiB table in LDS; level 30 sixteen waves, eleven with the table in LDS
 // and five with a u32-slot table in global memory; larger blocks run the all-LDS form (13 / 11 waves).
 template <bool HUF, bool MIXED>
@@ -146,13 +150,11 @@ void lz_fast12_kernel(LzBatch a)
         lz_wave_main<LZ_PARSER_FAST, 12, 0, HUF, (HUF ? LZ_WAVES_FASTLDS_HUF : LZ_WAVES_FASTLDS), (HUF ? LZ_HUF_WS_WORDS : 1),
                      (HUF ? LZ_WAVES_FASTLDS_HUF : LZ_WAVES_FASTLDS)>(a);
 }
+#endif   // !LZ_FAST12_SPLIT (the shipped library carries the producer / consumer form only)
 
 // levels 10 / 30, producer / consumer form (lz_split.h): NP waves with a 12 KiB table in LDS only parse, NC waves without a table
 // run the container (encode pass, huff0) of the sub-blocks the producers hand over.  Every block size: the 17-bit relative
 // positions of LzTab have no size limit.  LZ_FAST12_SPLIT=0 builds the one-wave-per-block form above instead (tuning variants).
-#ifndef LZ_FAST12_SPLIT
-#define LZ_FAST12_SPLIT 1
-#endif
 #ifndef LZ_SPLIT_PROD
 #define LZ_SPLIT_PROD 13
 #endif

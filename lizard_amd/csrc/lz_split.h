@@ -69,6 +69,7 @@ LZ_DEV u8* lz_split_buf(const LzSplitArgs& a, u32 bufIndex) { return a.arena + (
 #define LZ_SPLIT_CONS_BYTES (2u * LZ_SUBBLOCK_PAD + LZ_SPLIT_OPS_BYTES)
 LZ_DEV u8* lz_split_staging(const LzSplitArgs& a, u32 cons) { return a.arena + (u64)a.nProd * a.nBufs * LZ_SPLIT_BUF_BYTES + (u64)cons * LZ_SPLIT_CONS_BYTES; }
 #define LZ_SPLIT_ARENA_BYTES(nProd, nCons, nBufs) ((size_t)(nProd) * (nBufs) * LZ_SPLIT_BUF_BYTES + (size_t)(nCons) * LZ_SPLIT_CONS_BYTES)
+#define LZ_SPLIT_PROF_END ((u64)16u * LZ_SCRATCH_BYTES)       // profile builds: 16 x 128-byte records at the end of the workgroup's arena (LZ_MAX_WAVES slots)
 
 // ---- producer: claim blocks, parse their sub-blocks, publish one job per sub-block ----
 template <int HASHLOG>
@@ -103,6 +104,7 @@ LZ_DEV void lz_split_producer(const LzSplitArgs& a, const LzSplitShared& sh, u32
                 lz_sleep();
             }
             lz_lds_atomic_and(&sh.bufFree[prod], lane == 0 ? ~(1u << j) : 0xFFFFFFFFu);
+            LZ_PROF(st, 6);                                                      // (profile builds) waiting for a free sequence buffer
             const u32 bufIndex = prod * a.nBufs + j;
             u8* const buf = lz_split_buf(a, bufIndex);
             st.seq = (u64*)(buf + LZ_SPLIT_HDR);
@@ -122,11 +124,18 @@ LZ_DEV void lz_split_producer(const LzSplitArgs& a, const LzSplitShared& sh, u32
             const u32 t = lz_lds_claim(&sh.qTail[cons]);
             if (lane == 0) lz_lds_store(&sh.q[cons * a.qn + (t & (a.qn - 1u))], bufIndex + 1u);
             lz_converge();
+            LZ_PROF(st, 3);                                                      // job header, publish
             pos += part;
         }
     }
     lz_lds_atomic_add(sh.prodDone, lane == 0 ? 1u : 0u);
     lz_converge();
+#ifdef LZ_PROFILE
+    // per-wave totals: profile record `prod` at the END of the workgroup's arena (the scratch-slot tails of the one-wave form lie
+    // inside the sequence buffers here)
+    if (lane == 0) { u64* pr = (u64*)(a.arena + LZ_SPLIT_PROF_END - (u64)(prod + 1u) * 128u); for (int k = 0; k < 15; k++) pr[k] += st.prof[k]; }
+    lz_converge();
+#endif
 }
 
 // ---- consumer: take jobs from my mailbox, run the container of each, hand the buffer back ----
@@ -153,6 +162,7 @@ LZ_DEV void lz_split_consumer(const LzSplitArgs& a, const LzSplitShared& sh, u32
                 if (!word) break;
             } else { lz_sleep(); continue; }
         }
+        LZ_PROF(st, 7);                                                          // (profile builds) consumer: waiting for a job
         lz_publish_acquire();                                                    // the header and the list behind the word
         if (lane == 0) lz_lds_store(&sh.q[cons * a.qn + (head & (a.qn - 1u))], 0u);
         lz_converge();
@@ -179,5 +189,10 @@ LZ_DEV void lz_split_consumer(const LzSplitArgs& a, const LzSplitShared& sh, u32
         lz_converge();
         lz_wave_sync();
         lz_lds_atomic_or(&sh.bufFree[bufIndex / a.nBufs], lane == 0 ? 1u << (bufIndex % a.nBufs) : 0u);   // back to its producer
+        LZ_PROF(st, 5);                                                          // consumer: the container of one sub-block
     }
+#ifdef LZ_PROFILE
+    if (lane == 0) { u64* pr = (u64*)(a.arena + LZ_SPLIT_PROF_END - (u64)(a.nProd + cons + 1u) * 128u); for (int k = 0; k < 15; k++) pr[k] += st.prof[k]; }
+    lz_converge();
+#endif
 }

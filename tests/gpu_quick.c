@@ -125,9 +125,9 @@ int main(int argc, char** argv)
                 int (*dump)(unsigned long long*) = (int (*)(unsigned long long*))dlsym(RTLD_DEFAULT, "LizardGPU_profileDump");
                 unsigned long long pr[16];
                 if (dump && dump(pr) == 0) {
-                    static const char* nm[8] = { "roundA(bytes,hash,LDS,filter) | hc: rounds", "roundB(cand wait,settle) | hc: find_best", "extension | hc: wider #1", "glue+encode | hc: wider #2 + glue", "store drain", "container", "table init | hc: chain build", "-" };
+                    static const char* nm[8] = { "roundA(bytes,hash,LDS,filter) | hc: rounds", "roundB(cand wait,settle) | hc: find_best", "extension | hc: wider #1", "glue+encode | hc: wider #2 + glue", "store drain", "container (split form: consumers)", "table init | hc: chain build | split: producer waits for a buffer", "split: consumer waits for a job" };
                     double sum = 0; for (int k = 0; k < 8; k++) sum += (double)pr[k];   /* slots 8.. are sub-phases of the container slot */
-                    for (int k = 0; k < 7; k++) printf("    prof %-48s %6.2f %%  %.3g clk\n", nm[k], 100.0 * pr[k] / sum, (double)pr[k]);
+                    for (int k = 0; k < 8; k++) printf("    prof %-48s %6.2f %%  %.3g clk\n", nm[k], 100.0 * pr[k] / sum, (double)pr[k]);
                     printf("    prof raw:"); for (int k = 0; k < 15; k++) printf(" [%d]=%.4g", k, (double)pr[k]); printf("\n");
                     {   static const char* hn[7] = { "huf histogram | hc: chain walk", "huf rank sort | hc: measure", "huf lane-0 tree/codes/header | hc: select", "huf exact sizes", "huf bit packing", "-", "huf entry" };
                         for (int k = 8; k < 15; k++) if (pr[k]) printf("      (sub-phase) %-44s %6.2f %%\n", hn[k - 8], 100.0 * pr[k] / sum); }
