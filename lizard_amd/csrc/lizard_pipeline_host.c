@@ -68,6 +68,33 @@ static void par_memcpy(void* dst, const void* src, size_t n)
     for (i = 0; i < LZ_COPY_THREADS; i++) if (started[i]) pthread_join(th[i], NULL);
 }
 
+/* sizes / offsets of a stage, device and pinned host, for `n` entries.  A failure leaves nothing half-allocated behind. */
+static void free_meta(LzStage* s)
+{
+    if (s->d_sizes) (void)hipFree(s->d_sizes);
+    if (s->d_offsets) (void)hipFree(s->d_offsets);
+    if (s->h_sizes) (void)hipHostFree(s->h_sizes);
+    if (s->h_offsets) (void)hipHostFree(s->h_offsets);
+    s->d_sizes = NULL; s->d_offsets = NULL; s->h_sizes = NULL; s->h_offsets = NULL;
+    s->d_meta_cap = 0; s->h_meta_cap = 0;
+}
+static int ensure_meta(LzStage* s, size_t n)
+{
+    hipError_t e;
+    if (s->d_meta_cap >= n && s->h_meta_cap >= n) return 0;
+    free_meta(s);
+    if ((e = hipMalloc((void**)&s->d_sizes, n * sizeof(uint32_t))) == hipSuccess
+        && (e = hipMalloc((void**)&s->d_offsets, n * sizeof(uint64_t))) == hipSuccess
+        && (e = hipHostMalloc((void**)&s->h_sizes, n * sizeof(uint32_t), hipHostMallocDefault)) == hipSuccess
+        && (e = hipHostMalloc((void**)&s->h_offsets, n * sizeof(uint64_t), hipHostMallocDefault)) == hipSuccess) {
+        s->d_meta_cap = n; s->h_meta_cap = n;
+        return 0;
+    }
+    snprintf(lzk_err(), LZK_ERR_BYTES, "allocation of %zu size / offset entries failed: %s", n, hipGetErrorString(e));
+    free_meta(s);
+    return e == hipErrorOutOfMemory ? -LIZARDGPU_ERR_NOMEM : -LIZARDGPU_ERR_HIP;
+}
+
 static int is_pinned_host(const void* p)
 {
     hipPointerAttribute_t at;
@@ -110,22 +137,7 @@ static int stage_issue(LzCtx* c, LzStage* s, const HostJob* j, ChunkState* ch, i
     if ((rc = ensure_dev((void**)&s->d_slots, &s->d_slots_cap, ch->nb * slot))) return rc;
     if ((rc = ensure_dev((void**)&s->d_packed, &s->d_packed_cap, packedCap))) return rc;
     if ((rc = ensure_pinned((void**)&s->h_out, &s->h_out_cap, packedCap + 64))) return rc;    /* worst case once: a buffer that follows the chunks' sizes is re-pinned again and again */
-    if (s->d_meta_cap < ch->nb + 1) {
-        if (s->d_sizes) { LZ_HIP(hipFree(s->d_sizes)); s->d_sizes = NULL; }
-        if (s->d_offsets) { LZ_HIP(hipFree(s->d_offsets)); s->d_offsets = NULL; }
-        s->d_meta_cap = 0;
-        LZ_HIP(hipMalloc((void**)&s->d_sizes, (ch->nb + 1) * sizeof(uint32_t)));
-        LZ_HIP(hipMalloc((void**)&s->d_offsets, (ch->nb + 1) * sizeof(uint64_t)));
-        s->d_meta_cap = ch->nb + 1;
-    }
-    if (s->h_meta_cap < ch->nb + 1) {
-        if (s->h_sizes) { LZ_HIP(hipHostFree(s->h_sizes)); s->h_sizes = NULL; }
-        if (s->h_offsets) { LZ_HIP(hipHostFree(s->h_offsets)); s->h_offsets = NULL; }
-        s->h_meta_cap = 0;
-        LZ_HIP(hipHostMalloc((void**)&s->h_sizes, (ch->nb + 1) * sizeof(uint32_t), hipHostMallocDefault));
-        LZ_HIP(hipHostMalloc((void**)&s->h_offsets, (ch->nb + 1) * sizeof(uint64_t), hipHostMallocDefault));
-        s->h_meta_cap = ch->nb + 1;
-    }
+    if ((rc = ensure_meta(s, ch->nb + 1))) return rc;
     from = j->src + ch->first * j->blockSize;
     if (!srcPinned) {
         if ((rc = ensure_pinned((void**)&s->h_in, &s->h_in_cap, ch->inBytes))) return rc;
@@ -220,6 +232,12 @@ static int run_host_job_inner(LzCtx* c, const HostJob* j)
     if (rc) return rc;
     if (!j->src || j->nBlocks == 0 || j->blockSize == 0 || j->lastBlockSize == 0 || j->lastBlockSize > j->blockSize) {
         snprintf(lzk_err(), LZK_ERR_BYTES, "bad argument (null pointer, zero size or lastBlockSize > blockSize)");
+        return -LIZARDGPU_ERR_ARG;
+    }
+    /* what the launcher would refuse is refused HERE, before anything is allocated, pinned or copied */
+    if (!LizardGPU_levelSupported(j->level)) { snprintf(lzk_err(), LZK_ERR_BYTES, "level %d has no GPU kernel", lzk_clamp_level(j->level)); return -LIZARDGPU_ERR_LEVEL; }
+    if (j->blockSize > (size_t)LIZARD_MAX_INPUT_SIZE || j->nBlocks > 0xFFFFFFFFu) {
+        snprintf(lzk_err(), LZK_ERR_BYTES, "bad argument (blockSize above LIZARD_MAX_INPUT_SIZE or more than 2^32 - 1 blocks)");
         return -LIZARDGPU_ERR_ARG;
     }
     memset(&p, 0, sizeof p);

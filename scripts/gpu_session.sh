@@ -35,6 +35,6 @@ validate)
   find $O/rocprof -name "*.csv" -size +1M -delete; find $O/rocprof -name "*.db" -delete
   bash scripts/gpu_traffic.sh $TAG "10 262144 65536" "10 4194304 6656" "30 262144 16384" "21 262144 16384" "11 262144 16384" "13 262144 16384" > $O/traffic.log 2>&1
   grep -E "^L" $O/traffic.log | tee -a $O/summary.txt
-  for l in 11 31 13 14 15 16 17 35 22 41 42; do timeout 300 tests/gpu_bench $l 262144 16384 2 2>&1 | tail -1 | tee -a $O/summary.txt; done ;;
+  for l in 11 31 13 14 15 16 17 35 22 41 42; do timeout 300 tests/gpu_bench $l 262144 16384 2 50 1024 2>&1 | tail -1 | tee -a $O/summary.txt; done ;;
 *) echo "unknown mode $MODE"; exit 2 ;;
 esac
