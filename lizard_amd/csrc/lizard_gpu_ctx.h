@@ -26,7 +26,6 @@ typedef struct LzStage {
     uint32_t* d_sizes;  uint64_t* d_offsets;  size_t d_meta_cap;
 } LzStage;
 
-enum { LZ_PH_IDLE = 0, LZ_PH_COPY_IN, LZ_PH_GPU, LZ_PH_COPY_OUT };
 /* The combiner of the one-block entry points (Lizard_compress & co, lizard_pipeline_host.c): callers that arrive while a batch
  * is in flight queue up and leave together in the next launch.  Own staging and stream: the members of a batch copy their input
  * into h_in and their output out of h_out themselves, outside the context lock. */
@@ -35,10 +34,8 @@ typedef struct LzCombine {
     pthread_mutex_t mu;
     pthread_cond_t  cv;
     struct LzOneJob *head, *tail;       /* callers waiting for a batch */
-    int   busy;                         /* a batch is under way: from the moment its leader takes it until its last output has been copied out */
-    int   phase;                        /* LZ_PH_*: what the waiting threads can help with */
-    struct LzOneJob* cur[1024];         /* members of the current batch (LZ_ONE_MAX_JOBS) */
-    int   curN, nextCopy, doneCopy;     /* copies of the current phase: claimed / finished */
+    int   busy;                         /* a batch is under way: from the moment its leader takes it until its last member has copied out */
+    int   pendingIn, pendingOut;        /* members of the current batch that still have to copy in / out */
     LzStage st;                         /* staging of the current batch */
     uint32_t* d_srcSizes; uint64_t* d_srcOffsets; uint32_t* h_srcSizes; uint64_t* h_srcOffsets; size_t raggedCap;
     unsigned long long batches, jobs;   /* statistics (LizardGPU_combinerStats) */

@@ -406,9 +406,8 @@ typedef struct LzOneJob {
     char errText[LZK_ERR_BYTES];
     struct LzOneJob* next;
 } LzOneJob;
-enum { JOB_QUEUED = 0, JOB_MEMBER, JOB_DONE, JOB_FAILED };
+enum { JOB_QUEUED = 0, JOB_COPY_IN, JOB_COPIED_IN, JOB_RESULT, JOB_FAILED };
 #define LZ_ONE_MAX_JOBS   1024                  /* members per batch */
-static int help_copy(LzCombine* k);
 #define LZ_ONE_MAX_BYTES  ((size_t)1 << 30)     /* input bytes per batch */
 
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + (double)t.tv_nsec * 1e-9; }
@@ -504,7 +503,7 @@ void lzk_combiner_free(LzCtx* c)                /* context locked, no batch unde
 void lzk_combiner_quiesce(LzCtx* c)
 {
     pthread_mutex_lock(&c->comb.mu);
-    while (c->comb.busy) { if (!help_copy(&c->comb)) pthread_cond_wait(&c->comb.cv, &c->comb.mu); }
+    while (c->comb.busy) pthread_cond_wait(&c->comb.cv, &c->comb.mu);
     c->comb.busy = 1;                           /* callers queue up until lzk_combiner_resume */
     pthread_mutex_unlock(&c->comb.mu);
 }
@@ -516,52 +515,12 @@ void lzk_combiner_resume(LzCtx* c)
     pthread_mutex_unlock(&c->comb.mu);
 }
 
-/* The host copies of a batch are shared work: whoever is awake does them.  Called with comb.mu held by ANY thread that is waiting
- * in lzgpu_compress_one (members of the batch and callers queued for the next one alike): claims members one at a time and copies
- * their inputs into the staging (phase COPY_IN) or their outputs out of it, applying the reference's maxDstSize contract (phase
- * COPY_OUT).  With 64 callers on 16 cores the threads that wake first do most of it, and nobody waits for the last one to wake:
- * a member whose job was finished by a helper just returns.  Returns 1 if it did any work (the caller re-checks its own job). */
-static int help_copy(LzCombine* k)
-{
-    int worked = 0;
-    while (k->phase == LZ_PH_COPY_IN && k->nextCopy < k->curN) {
-        LzOneJob* j = k->cur[k->nextCopy++];
-        pthread_mutex_unlock(&k->mu);
-        memcpy(k->st.h_in + j->inOff, j->src, (size_t)j->srcSize);
-        pthread_mutex_lock(&k->mu);
-        worked = 1;
-        if (++k->doneCopy == k->curN) pthread_cond_broadcast(&k->cv);
-    }
-    while (k->phase == LZ_PH_COPY_OUT && k->nextCopy < k->curN) {
-        LzOneJob* j = k->cur[k->nextCopy++];
-        int result;
-        pthread_mutex_unlock(&k->mu);
-        /* The reference's room checks compare against oend = dst + maxDstSize (lizard_compress.c:238, :489): whatever fits is
-         * written.  A ONE-byte block is the case the reference gets through by accident: Lizard_compress_generic decrements
-         * maxOutputSize after the level byte, writeBlock's raw branch tests `*op + blockSize + 4 > oend` only for the sub-block,
-         * and with maxDstSize = srcSize - 1 = 0 (the frame layer's call, lizard_frame.c:461) the unsigned room test wraps: the
-         * 6-byte block (level, 0x80, LE24 1, the byte) is emitted and its size returned.  Same here. */
-        if ((int)j->csize > j->maxDst && !(j->srcSize == 1 && j->maxDst == 0)) result = 0;
-        else { memcpy(j->dst, j->out, j->csize); result = (int)j->csize; }
-        pthread_mutex_lock(&k->mu);
-        worked = 1;
-        j->result = result;
-        j->state = JOB_DONE;
-        if (++k->doneCopy == k->curN) {          /* the staging is free for the next batch */
-            k->tOut += now_s() - k->tBusySince;
-            k->phase = LZ_PH_IDLE; k->busy = 0;
-        }
-        pthread_cond_broadcast(&k->cv);
-    }
-    return worked;
-}
-
 /* Called with comb.mu held by a caller whose job is queued and that found no batch under way: runs one batch (its own job is
- * in it) up to the point where the compressed blocks sit in the pinned output.  Returns with comb.mu held. */
+ * in it) up to the point where every member knows its result.  Returns with comb.mu held. */
 static void lead_batch(LzCtx* c, LzOneJob* mine)
 {
     LzCombine* k = &c->comb;
-    LzOneJob** const jobs = k->cur;
+    LzOneJob* jobs[LZ_ONE_MAX_JOBS];
     LzOneJob *j, *keepHead = NULL, *keepTail = NULL;
     size_t inBytes = 0, maxSize = 0;
     const int level = mine->level;
@@ -587,7 +546,6 @@ static void lead_batch(LzCtx* c, LzOneJob* mine)
     }
     k->head = keepHead; k->tail = keepTail;
     k->batches++; k->jobs += (unsigned long long)n;
-    for (i = 0; i < n; i++) jobs[i]->state = JOB_MEMBER;
     pthread_mutex_unlock(&k->mu);
 
     lzk_guard_acquire(&g);                      /* context lock + this device current */
@@ -595,13 +553,15 @@ static void lead_batch(LzCtx* c, LzOneJob* mine)
     if (!rc) rc = batch_buffers(c, n, inBytes, maxSize);
     t1 = t2 = now_s();
     if (!rc) {
-        /* the inputs into the staging: every waiting thread helps (help_copy), this one too */
+        /* every member copies its own input in (mine: here) */
         pthread_mutex_lock(&k->mu);
-        k->curN = n; k->nextCopy = 0; k->doneCopy = 0; k->phase = LZ_PH_COPY_IN;
+        k->pendingIn = n - 1;
+        for (i = 0; i < n; i++) if (jobs[i] != mine) jobs[i]->state = JOB_COPY_IN;
         pthread_cond_broadcast(&k->cv);
-        help_copy(k);
-        while (k->doneCopy < n) pthread_cond_wait(&k->cv, &k->mu);
-        k->phase = LZ_PH_GPU;
+        pthread_mutex_unlock(&k->mu);
+        memcpy(k->st.h_in + mine->inOff, mine->src, (size_t)mine->srcSize);
+        pthread_mutex_lock(&k->mu);
+        while (k->pendingIn) pthread_cond_wait(&k->cv, &k->mu);
         pthread_mutex_unlock(&k->mu);
         t2 = now_s();
         rc = batch_on_gpu(c, jobs, n, inBytes, maxSize, level);
@@ -612,11 +572,10 @@ static void lead_batch(LzCtx* c, LzOneJob* mine)
 
     pthread_mutex_lock(&k->mu);
     k->tLock += t1 - t0; k->tCopyIn += t2 - t1; k->tGpu += t3 - t2; k->tBusySince = t3;
-    if (rc) {
-        for (i = 0; i < n; i++) { jobs[i]->state = JOB_FAILED; jobs[i]->result = rc; memcpy(jobs[i]->errText, lzk_err(), LZK_ERR_BYTES); }
-        k->phase = LZ_PH_IDLE; k->busy = 0;
-    } else {
-        k->curN = n; k->nextCopy = 0; k->doneCopy = 0; k->phase = LZ_PH_COPY_OUT;
+    k->pendingOut = n;
+    for (i = 0; i < n; i++) {
+        if (rc) { jobs[i]->state = JOB_FAILED; jobs[i]->result = rc; memcpy(jobs[i]->errText, lzk_err(), LZK_ERR_BYTES); }
+        else jobs[i]->state = JOB_RESULT;
     }
     pthread_cond_broadcast(&k->cv);
 }
@@ -641,13 +600,31 @@ int lzgpu_compress_one(const void* src, int srcSize, void* dst, int maxDstSize, 
     if (k->tail) k->tail->next = &job; else k->head = &job;
     k->tail = &job;
     for (;;) {
-        if (job.state == JOB_DONE || job.state == JOB_FAILED) break;
         if (job.state == JOB_QUEUED && !k->busy) { lead_batch(c, &job); continue; }
-        if (help_copy(k)) continue;
+        if (job.state == JOB_COPY_IN) {
+            pthread_mutex_unlock(&k->mu);
+            memcpy(k->st.h_in + job.inOff, src, (size_t)srcSize);
+            pthread_mutex_lock(&k->mu);
+            job.state = JOB_COPIED_IN;
+            if (--k->pendingIn == 0) pthread_cond_broadcast(&k->cv);
+            continue;
+        }
+        if (job.state == JOB_RESULT || job.state == JOB_FAILED) break;
         pthread_cond_wait(&k->cv, &k->mu);
     }
     pthread_mutex_unlock(&k->mu);
-    if (job.state == JOB_FAILED) memcpy(lzk_err(), job.errText, LZK_ERR_BYTES);
+    if (job.state == JOB_RESULT) {
+        /* The reference's room checks compare against oend = dst + maxDstSize (lizard_compress.c:238, :489): whatever fits is
+         * written.  A ONE-byte block is the case the reference gets through by accident: Lizard_compress_generic decrements
+         * maxOutputSize after the level byte, writeBlock's raw branch tests `*op + blockSize + 4 > oend` only for the sub-block,
+         * and with maxDstSize = srcSize - 1 = 0 (the frame layer's call, lizard_frame.c:461) the unsigned room test wraps: the
+         * 6-byte block (level, 0x80, LE24 1, the byte) is emitted and its size returned.  Same here. */
+        if ((int)job.csize > maxDstSize && !(srcSize == 1 && maxDstSize == 0)) job.result = 0;
+        else { memcpy(dst, job.out, job.csize); job.result = (int)job.csize; }
+    } else memcpy(lzk_err(), job.errText, LZK_ERR_BYTES);
+    pthread_mutex_lock(&k->mu);                 /* the staging is free for the next batch once the last member has left */
+    if (--k->pendingOut == 0) { k->tOut += now_s() - k->tBusySince; k->busy = 0; pthread_cond_broadcast(&k->cv); }
+    pthread_mutex_unlock(&k->mu);
     return job.result;
 }
 
