@@ -36,6 +36,7 @@ typedef struct LzCombine {
     struct LzOneJob *head, *tail;       /* callers waiting for a batch */
     int   busy;                         /* a batch is under way: from the moment its leader takes it until its last member has copied out */
     int   pendingIn, pendingOut;        /* members of the current batch that still have to copy in / out */
+    int   queued, lastN, collecting;    /* callers in the queue; members of the previous batch; a leader is waiting for stragglers */
     LzStage st;                         /* staging of the current batch */
     uint32_t* d_srcSizes; uint64_t* d_srcOffsets; uint32_t* h_srcSizes; uint64_t* h_srcOffsets; size_t raggedCap;
     unsigned long long batches, jobs;   /* statistics (LizardGPU_combinerStats) */

@@ -409,6 +409,9 @@ typedef struct LzOneJob {
 enum { JOB_QUEUED = 0, JOB_COPY_IN, JOB_COPIED_IN, JOB_RESULT, JOB_FAILED };
 #define LZ_ONE_MAX_JOBS   1024                  /* members per batch */
 #define LZ_ONE_MAX_BYTES  ((size_t)1 << 30)     /* input bytes per batch */
+#ifndef LZ_ONE_WINDOW_US
+#define LZ_ONE_WINDOW_US  150L                  /* longest a leader waits for the stragglers of the previous batch */
+#endif
 
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + (double)t.tv_nsec * 1e-9; }
 
@@ -529,6 +532,18 @@ static void lead_batch(LzCtx* c, LzOneJob* mine)
     double t0, t1, t2, t3;
     k->busy = 1;
     t0 = now_s();
+    /* A launch takes the same ~3 ms whatever it carries: blocks per launch is what counts.  The callers of the previous batch come
+     * back one by one; a leader that finds fewer of them queued than that batch had gives the stragglers a moment (at most
+     * LZ_ONE_WINDOW_US) before it takes the queue.  A lone caller never waits (lastN == 1). */
+    if (k->queued < k->lastN) {
+        struct timespec until;
+        clock_gettime(CLOCK_REALTIME, &until);
+        until.tv_nsec += LZ_ONE_WINDOW_US * 1000L;
+        if (until.tv_nsec >= 1000000000L) { until.tv_nsec -= 1000000000L; until.tv_sec += 1; }
+        k->collecting = 1;
+        while (k->queued < k->lastN && pthread_cond_timedwait(&k->cv, &k->mu, &until) == 0) {}
+        k->collecting = 0;
+    }
     /* members: my job and every queued job of my level, in arrival order, while they fit; the others stay queued */
     for (j = k->head; j; ) {
         LzOneJob* const next = j->next;
@@ -545,6 +560,7 @@ static void lead_batch(LzCtx* c, LzOneJob* mine)
         j = next;
     }
     k->head = keepHead; k->tail = keepTail;
+    k->queued -= n; k->lastN = n;
     k->batches++; k->jobs += (unsigned long long)n;
     pthread_mutex_unlock(&k->mu);
 
@@ -599,6 +615,8 @@ int lzgpu_compress_one(const void* src, int srcSize, void* dst, int maxDstSize, 
     pthread_mutex_lock(&k->mu);
     if (k->tail) k->tail->next = &job; else k->head = &job;
     k->tail = &job;
+    k->queued++;
+    if (k->collecting) pthread_cond_broadcast(&k->cv);      /* a leader is waiting for stragglers */
     for (;;) {
         if (job.state == JOB_QUEUED && !k->busy) { lead_batch(c, &job); continue; }
         if (job.state == JOB_COPY_IN) {
