@@ -413,3 +413,22 @@ def test_xxhash_matches_the_specification(lib):
         assert lib.Lizard_XXH32_digest(a32) == xxhash.xxh32(blob[:n], seed=seed).intdigest()
         assert lib.Lizard_XXH64_digest(a64) == xxhash.xxh64(blob[:n], seed=seed).intdigest()
         assert guard_ok(st32, 48) and guard_ok(st64, 88)
+
+
+def test_decoder_and_frame_decoder_under_sanitizers(tmp_path):
+    """tests/decode_fuzz.c: the three host sources of the decode / frame / hash half built with AddressSanitizer +
+    UndefinedBehaviorSanitizer (no HIP needed), valid and damaged blocks and frames in exact-size heap buffers — an access one
+    byte outside any buffer, a signed overflow or a misaligned access aborts the run."""
+    import subprocess
+    exe = str(tmp_path / "decode_fuzz")
+    csrc = os.path.join(util.ROOT, "lizard_amd", "csrc")
+    util.oracle()
+    subprocess.check_call(["gcc", "-O1", "-g", "-std=gnu99", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           os.path.join(util.ROOT, "tests", "decode_fuzz.c"), os.path.join(csrc, "lizard_decode_host.c"),
+                           os.path.join(csrc, "lizard_frame_host.c"), os.path.join(csrc, "lizard_xxhash.c"),
+                           "-I" + os.path.join(util.ROOT, "include"), "-I" + util.ORACLE_DIR, "-L" + util.ORACLE_DIR, "-llizard_oracle",
+                           "-lpthread", "-Wl,-rpath," + util.ORACLE_DIR, "-o", exe])
+    for seed in (11, 12):
+        r = subprocess.run([exe, str(seed), "400"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        assert "0 misbehaved" in r.stdout
