@@ -110,7 +110,11 @@ LZ_DEV void lz_split_producer(const LzSplitArgs& a, const LzSplitShared& sh, u32
             st.seq = (u64*)(buf + LZ_SPLIT_HDR);
             st.nlit = st.nflags = st.noff16 = st.noff24 = 0;                      // Lizard_initBlock, lizard_compress.c:130-138
             st.nseq = 0; st.lastLits = 0;
+#if LZ_FAST_128
+            lz_parse_fast128<HASHLOG>(src, pos, pos + part, tab, st);
+#else
             lz_parse_fast<HASHLOG>(src, pos, pos + part, tab, st);
+#endif
             // the job header
             {
                 const u32 flags = (pos == 0 ? LZJ_FIRST : 0u) | (pos + part >= n ? LZJ_LAST : 0u);

@@ -208,6 +208,17 @@ LZ_DEV void lz_lds_mskor_rtn2(LZ_LDS u32* pa, u32 ma, u32 va, LZ_LDS u32* pb, u3
                  : "v"((u32)(uintptr_t)pa), "v"(ma), "v"(va), "v"((u32)(uintptr_t)pb), "v"(mb), "v"(vb) : "memory");
 }
 
+// The same for TWO slots per lane in one round trip: a's pair, then b's pair, one wait.  The LDS unit executes the four instructions
+// in order, so every lane's b-exchange sees all 64 a-exchanges (128 exchanges in the order a0..a63, b0..b63).
+LZ_DEV void lz_lds_mskor_rtn4(LZ_LDS u32* pa, u32 ma, u32 va, LZ_LDS u32* pb, u32 mb, u32 vb, LZ_LDS u32* pc, u32 mc, u32 vc, LZ_LDS u32* pd, u32 md, u32 vd,
+                              u32& oa, u32& ob, u32& oc, u32& od)
+{
+    asm volatile("ds_mskor_rtn_b32 %0, %4, %5, %6\n\tds_mskor_rtn_b32 %1, %7, %8, %9\n\tds_mskor_rtn_b32 %2, %10, %11, %12\n\tds_mskor_rtn_b32 %3, %13, %14, %15\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(oa), "=&v"(ob), "=&v"(oc), "=&v"(od)
+                 : "v"((u32)(uintptr_t)pa), "v"(ma), "v"(va), "v"((u32)(uintptr_t)pb), "v"(mb), "v"(vb),
+                   "v"((u32)(uintptr_t)pc), "v"(mc), "v"(vc), "v"((u32)(uintptr_t)pd), "v"(md), "v"(vd) : "memory");
+}
+
 // Returning exchange / add on an LDS dword; every lane of the wave takes part (lanes with nothing to do aim at a spare word).
 // Lane order as above: lane l receives what the closest lower lane of the same dword left behind — lz_lds_add_rtn with 1 hands
 // out consecutive slots in lane order (a stable partition step), lz_lds_xchg_rtn is "read the head, become the head".

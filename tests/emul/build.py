@@ -11,12 +11,20 @@ DEPS = SRCS + [os.path.join(HERE, "lz_wave.h")] + [
 
 
 def build(force=False):
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
-        return OUT
+    """LZ_EMUL_DEFS="-DLZ_FAST_128=1": emulate a tuning variant of the kernels (built beside the default library, picked up by
+    util.emulator() for the lifetime of that environment variable) — e.g. LZ_EMUL_DEFS=-DLZ_FAST_128=1 python scripts/emul_fuzz.py 1 60 300000 long 10,30"""
+    defs = os.environ.get("LZ_EMUL_DEFS", "").split()
+    out = OUT if not defs else os.path.join(HERE, "libemul_variant.so")
+    stamp = out + ".defs"
+    same = not defs or (os.path.exists(stamp) and open(stamp).read() == " ".join(defs))
+    if not force and same and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in DEPS):
+        return out
     cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-fno-omit-frame-pointer", "-Wall", "-Wextra",
-           "-Wno-unused-function", "-Wno-unknown-pragmas", "-pthread", "-I", HERE, "-o", OUT] + SRCS
+           "-Wno-unused-function", "-Wno-unknown-pragmas", "-pthread", "-I", HERE, "-o", out] + defs + SRCS
     subprocess.check_call(cmd)
-    return OUT
+    if defs:
+        open(stamp, "w").write(" ".join(defs))
+    return out
 
 
 if __name__ == "__main__":

@@ -158,6 +158,12 @@ LZ_DEV void lz_lds_mskor_rtn2(u32* pa, u32 ma, u32 va, u32* pb, u32 mb, u32 vb, 
     lzemu::park(lzemu::OP_MSKOR2);
     oa = w->xo[0][me]; ob = w->xo[1][me];
 }
+// two slots per lane: the a-pair of every lane, then the b-pair of every lane (the LDS unit executes the instructions in order)
+LZ_DEV void lz_lds_mskor_rtn4(u32* pa, u32 ma, u32 va, u32* pb, u32 mb, u32 vb, u32* pc, u32 mc, u32 vc, u32* pd, u32 md, u32 vd, u32& oa, u32& ob, u32& oc, u32& od)
+{
+    lz_lds_mskor_rtn2(pa, ma, va, pb, mb, vb, oa, ob);
+    lz_lds_mskor_rtn2(pc, mc, vc, pd, md, vd, oc, od);
+}
 LZ_DEV void lz_lds_mskor(u32* p, u32 mask, u32 val) { *p = (*p & ~mask) | val; }
 // returning exchange (kind 0) / add (kind 1), all lanes take part, served in ascending lane order
 LZ_DEV u32 lz_lds_atom1(u32* p, u32 v, u32 kind)

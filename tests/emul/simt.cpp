@@ -72,7 +72,10 @@ void run_wave(void (*entry)(void*), void* arg, u32 seed)
         case OP_READLANE: {
             u64 s = w->arg1[0];
             for (int l = 1; l < LZ_WAVE; l++)
-                if (w->arg1[l] != s) { fprintf(stderr, "lzemu: lz_readlane with a non-uniform lane index\n"); abort(); }
+                if (w->arg1[l] != s) {
+                    fprintf(stderr, "lzemu: lz_readlane with a non-uniform lane index (lane 0: %llu, lane %d: %llu; values", (unsigned long long)s, l, (unsigned long long)w->arg1[l]);
+                    for (int k = 0; k < LZ_WAVE; k += 8) fprintf(stderr, " [%d]=%llu", k, (unsigned long long)w->arg1[k]);
+                    fprintf(stderr, ")\n"); abort(); }
             if (s >= LZ_WAVE) { fprintf(stderr, "lzemu: lz_readlane index %llu out of range\n", (unsigned long long)s); abort(); }
             for (int l = 0; l < LZ_WAVE; l++) w->res[l] = w->arg0[s];
             break; }
