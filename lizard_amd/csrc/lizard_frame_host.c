@@ -193,23 +193,54 @@ size_t LizardF_compressBegin(LizardF_compressionContext_t c, void* dstBuffer, si
 
 /* The block records of nb blocks (blockSize each, the last one `last` bytes) at src, packed into dst: one batch on the GPU.
  * Non-strict contexts degrade like the reference's frame layer does when Lizard_compress_extState returns 0 (:456-469): every
- * block of the batch is stored raw, after one line on stderr. */
+ * block of the batch is stored raw, after one line on stderr.
+ *
+ * `reserve` = bytes of dst the caller still needs after the records (the end mark and content checksum that
+ * LizardF_compressBound counts, :443).  It matters for ONE input: a 1-byte block.  The reference compresses it into a 6-byte
+ * block (its room test wraps at maxDstSize 0, lizard_compress.c:238) and so writes a 10-byte record where LizardF_compressBound
+ * counted 5 — with a buffer of exactly the bound and nothing saved elsewhere it runs up to 5 bytes past dstMaxSize
+ * (LizardF_compressEnd has no room test, :651-677).  This library never writes past dstMaxSize: when the faithful record leaves
+ * less than `reserve`, a non-strict context stores that one byte raw (a 5-byte record, what the bound counted; same content
+ * for every decoder), a strict one reports dstMaxSize_tooSmall. */
+static void raw_record(uint8_t* dst, const uint8_t* src, size_t n)
+{
+    wr32le(dst, (uint32_t)n | 0x80000000u);
+    memcpy(dst + 4, src, n);
+}
+
 static int frame_records(LizardF_compressionContext_t c, const uint8_t* src, size_t nb, size_t blockSize, size_t last,
-                         uint8_t* dst, size_t cap, size_t* written)
+                         uint8_t* dst, size_t cap, size_t reserve, size_t* written)
 {
     static int warned = 0;
+    const int onGpu = LizardGPU_levelSupported(c->level);
     size_t i, need;
-    if (LizardGPU_levelSupported(c->level) && lzgpu_frame_records(src, nb, blockSize, last, dst, cap, written, c->level) == 0) return 0;
-    if (c->strict) return -1;
+    if (onGpu && lzgpu_frame_records(src, nb, blockSize, last, dst, cap, written, c->level) == 0) {
+        const size_t w = *written;
+        if (last == 1 && !c->strict && cap - w < reserve && w >= 10 && rd32le(dst + w - 10) == 6u) {      /* see above */
+            raw_record(dst + w - 10, src + (nb - 1) * blockSize, 1);
+            *written = w - 5;
+        }
+        return 0;
+    }
+    if (c->strict) return (onGpu && last == 1 && cap < (nb - 1) * (blockSize + 4) + 10) ? -2 : -1;     /* -2: that record cannot fit */
+    if (onGpu && last == 1 && cap < (nb - 1) * (blockSize + 4) + 10 + reserve) {
+        /* the batch may have failed only for the 1-byte block's 10-byte record: the others on the GPU, that byte raw */
+        size_t w = 0;
+        if (nb == 1 || lzgpu_frame_records(src, nb - 1, blockSize, blockSize, dst, cap, &w, c->level) == 0) {
+            if (cap - w < 5) return -1;
+            raw_record(dst + w, src + (nb - 1) * blockSize, 1);
+            *written = w + 5;
+            return 0;
+        }
+    }
     if (!__atomic_exchange_n(&warned, 1, __ATOMIC_RELAXED))
         fprintf(stderr, "liblizard_amd: frame blocks at level %d are stored uncompressed: %s (no CPU fallback in this library)\n", c->level,
-                LizardGPU_levelSupported(c->level) ? LizardGPU_lastError() : "level not implemented on the GPU path");
+                onGpu ? LizardGPU_lastError() : "level not implemented on the GPU path");
     need = (nb - 1) * (blockSize + 4) + last + 4;
     if (need > cap) return -1;
     for (i = 0; i < nb; i++) {
         const size_t n = i + 1 == nb ? last : blockSize;
-        wr32le(dst, (uint32_t)n | 0x80000000u);
-        memcpy(dst + 4, src + i * blockSize, n);
+        raw_record(dst, src + i * blockSize, n);
         dst += 4 + n;
     }
     *written = need;
@@ -231,9 +262,10 @@ size_t LizardF_compressUpdate(LizardF_compressionContext_t c, void* dstBuffer, s
     pthread_t th;
     struct crc_job job;
     int threaded = 0;
-    size_t result = 0;
+    size_t result = 0, frameEnd;
     (void)compressOptionsPtr;
     if (!c || c->stage != 1) return LZF_ERR(GENERIC);
+    frameEnd = 4 + (size_t)c->prefs.frameInfo.contentChecksumFlag * 4;                                /* part of LizardF_compressBound, :443 */
     if (dstMaxSize < LizardF_compressBound(srcSize, &c->prefs)) return LZF_ERR(dstMaxSize_tooSmall);
     if (c->prefs.frameInfo.contentChecksumFlag == 1 && srcSize) {                                    /* :593-594, beside the GPU work */
         job.st = &c->xxh; job.data = srcBuffer; job.len = srcSize;
@@ -250,7 +282,7 @@ size_t LizardF_compressUpdate(LizardF_compressionContext_t c, void* dstBuffer, s
             } else {
                 memcpy(c->tmpIn + c->tmpInSize, src, need);
                 src += need;
-                if (frame_records(c, c->tmpIn, 1, c->blockSize, c->blockSize, dst, (size_t)(dstEnd - dst), &w)) { result = LZF_ERR(GENERIC); break; }
+                if (frame_records(c, c->tmpIn, 1, c->blockSize, c->blockSize, dst, (size_t)(dstEnd - dst), 0, &w)) { result = LZF_ERR(GENERIC); break; }
                 dst += w;
                 c->tmpInSize = 0;
             }
@@ -261,7 +293,8 @@ size_t LizardF_compressUpdate(LizardF_compressionContext_t c, void* dstBuffer, s
             const size_t nb = full + ((c->prefs.autoFlush && tail) ? 1 : 0);
             if (nb) {
                 const size_t last = (c->prefs.autoFlush && tail) ? tail : c->blockSize;
-                if (frame_records(c, src, nb, c->blockSize, last, dst, (size_t)(dstEnd - dst), &w)) { result = LZF_ERR(GENERIC); break; }
+                const int e = frame_records(c, src, nb, c->blockSize, last, dst, (size_t)(dstEnd - dst), frameEnd, &w);
+                if (e) { result = e == -2 ? LZF_ERR(dstMaxSize_tooSmall) : LZF_ERR(GENERIC); break; }
                 dst += w;
                 src += (nb - 1) * c->blockSize + last;
             }
@@ -278,27 +311,39 @@ size_t LizardF_compressUpdate(LizardF_compressionContext_t c, void* dstBuffer, s
 }
 
 /* LizardF_flush, lizard_frame.c:610-637 */
-size_t LizardF_flush(LizardF_compressionContext_t c, void* dstBuffer, size_t dstMaxSize, const LizardF_compressOptions_t* compressOptionsPtr)
+static size_t flush_buffered(LizardF_compressionContext_t c, void* dstBuffer, size_t dstMaxSize, size_t reserve)
 {
     size_t w = 0;
-    (void)compressOptionsPtr;
     if (!c) return LZF_ERR(GENERIC);
     if (c->tmpInSize == 0) return 0;
     if (c->stage != 1) return LZF_ERR(GENERIC);
     if (dstMaxSize < c->tmpInSize + 8) return LZF_ERR(dstMaxSize_tooSmall);
-    if (frame_records(c, c->tmpIn, 1, c->tmpInSize, c->tmpInSize, (uint8_t*)dstBuffer, dstMaxSize, &w)) return LZF_ERR(GENERIC);
+    {
+        const int e = frame_records(c, c->tmpIn, 1, c->tmpInSize, c->tmpInSize, (uint8_t*)dstBuffer, dstMaxSize, reserve, &w);
+        if (e) return e == -2 ? LZF_ERR(dstMaxSize_tooSmall) : LZF_ERR(GENERIC);
+    }
     c->tmpInSize = 0;
     return w;
+}
+
+size_t LizardF_flush(LizardF_compressionContext_t c, void* dstBuffer, size_t dstMaxSize, const LizardF_compressOptions_t* compressOptionsPtr)
+{
+    (void)compressOptionsPtr;
+    return flush_buffered(c, dstBuffer, dstMaxSize, 0);
 }
 
 /* LizardF_compressEnd, lizard_frame.c:651-677 */
 size_t LizardF_compressEnd(LizardF_compressionContext_t c, void* dstBuffer, size_t dstMaxSize, const LizardF_compressOptions_t* compressOptionsPtr)
 {
     uint8_t* dst = (uint8_t*)dstBuffer;
-    const size_t f = LizardF_flush(c, dstBuffer, dstMaxSize, compressOptionsPtr);
+    size_t f, frameEnd;
+    (void)compressOptionsPtr;
+    if (!c) return LZF_ERR(GENERIC);
+    frameEnd = 4 + (size_t)c->prefs.frameInfo.contentChecksumFlag * 4;
+    f = flush_buffered(c, dstBuffer, dstMaxSize, frameEnd);
     if (LizardF_isError(f)) return f;
     dst += f;
-    if (dstMaxSize - f < 4 + (size_t)c->prefs.frameInfo.contentChecksumFlag * 4) return LZF_ERR(dstMaxSize_tooSmall);
+    if (dstMaxSize - f < frameEnd) return LZF_ERR(dstMaxSize_tooSmall);                                /* the reference writes regardless */
     wr32le(dst, 0); dst += 4;
     if (c->prefs.frameInfo.contentChecksumFlag == 1) { wr32le(dst, Lizard_XXH32_digest(&c->xxh)); dst += 4; }
     c->stage = 0;

@@ -389,6 +389,56 @@ def test_frames_without_a_gpu_store_raw_and_round_trip(lib):
         assert _my_frame_decode(lib, frame, len(data), random.Random(2), max_in=50000, max_out=30000) == data
 
 
+@pytest.mark.gpu
+def test_one_byte_tail_block_in_a_buffer_of_exactly_the_bound(lib):
+    """A 1-byte block costs the reference a 10-byte record where LizardF_compressBound counted 5 (the room test of
+    lizard_compress.c:238 wraps at maxDstSize 0).  With dst = LizardF_compressFrameBound exactly, a 15-byte header and
+    nothing saved on the other blocks the reference writes past the bound (found by tests/frametest.c, seed 7254 #1031);
+    this library stays inside dstMaxSize: LizardF_compressFrame stores that byte raw when the faithful record would not
+    leave room for the end mark, the strict twin reports dstMaxSize_tooSmall, and whenever the faithful frame fits it is
+    the one produced."""
+    lib.LizardF_compressFrameBound.argtypes = [C.c_size_t, C.c_void_p]
+    lib.LizardF_compressFrame.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.LizardGPU_compressFrame.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.LizardGPU_compressFrame.restype = C.c_size_t
+    noise = random.Random(5).randbytes(131072)
+    inputs = [b"Q", noise + b"Q", noise + noise[::-1] + b"Q", util.datagen(131072, 0.5, 0.0, 2) + b"Q"]
+    squeezed = 0
+    for data in inputs:
+        for level in (10, 21, 30):
+            for crc in (0, 1):
+                for csz in (0, 1):
+                    p = util.frame_prefs(level, 1, crc, csz)
+                    cap = lib.LizardF_compressFrameBound(len(data), C.byref(p))
+                    faithful = util.compose_frame(data, level, 1, crc, csz, util.oracle_compress)
+                    for fn in (lib.LizardF_compressFrame, lib.LizardGPU_compressFrame):
+                        dst = guarded(cap)
+                        n = fn(C.addressof(dst) + GUARD, cap, data, len(data), C.byref(p))
+                        assert guard_ok(dst, cap), "frame compressor wrote outside dstMaxSize"
+                        if len(faithful) <= cap:
+                            assert not lib.LizardF_isError(n) and bytes(dst)[GUARD:GUARD + n] == faithful
+                        elif fn is lib.LizardGPU_compressFrame:
+                            assert n == (1 << 64) - 11                                      # refused: dstMaxSize_tooSmall
+                        else:
+                            squeezed += 1
+                            assert not lib.LizardF_isError(n) and n <= cap and n == len(faithful) - 5
+                            frame = bytes(dst)[GUARD:GUARD + n]
+                            assert frame[:-4 - 4 * crc - 5] == faithful[:-4 - 4 * crc - 10]     # everything before the last record
+                            assert _my_frame_decode(lib, frame, len(data), random.Random(1)) == data
+                            R = stock()
+                            if R is not None:
+                                back = C.create_string_buffer(len(data) + 16)
+                                d = C.c_void_p()
+                                R.LizardF_createDecompressionContext.argtypes = [C.c_void_p, C.c_uint]
+                                R.LizardF_decompress.restype = C.c_size_t
+                                R.LizardF_decompress.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p]
+                                R.LizardF_createDecompressionContext(C.byref(d), 100)
+                                ds, ss = C.c_size_t(len(data) + 16), C.c_size_t(n)
+                                assert R.LizardF_decompress(d, back, C.byref(ds), frame, C.byref(ss), None) == 0
+                                assert back.raw[:ds.value] == data
+    assert squeezed >= 6          # the 1-byte input and the all-raw inputs with a content size in the header
+
+
 def test_xxhash_matches_the_specification(lib):
     import xxhash
     rnd = random.Random(9)
