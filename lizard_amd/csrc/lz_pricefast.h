@@ -231,6 +231,358 @@ LZ_DEV void lz_encode_lizv1(const u8* src, u32 S, const LzStreams& st, u8* litOu
 #ifndef LZ_PF_W0
 #define LZ_PF_W0 32u
 #endif
+// ---- several sequences out of one round (round 4) ----
+// A round has paid for 64 consecutive positions: every lane holds its slot's value as the reference's serial walk would have found
+// it (the same-slot replay), its hash candidate's bytes and its repeat-offset test.  The reference's next steps behind a winner are
+// all positions of this round as long as the sequence ends inside it:
+//   * the lazy step (pricefast.h:184-228) probes start2 = ip + ml - 2 — a lane of the round: its slot value, check bits, candidate
+//     bytes (24 forward, 8 backward) are in registers, so Lizard_FindMatchFaster (:90-128) costs no table access and no memory trip,
+//     and its conditional put (:190-191) is that lane's own put: the lane is simply committed;
+//   * the next search (:158-173) probes ip' = end of the sequence, ip' + 1, ... — the lanes from ip' - ip0 on.  Their hash side is
+//     unchanged; their repeat-offset side (:19-31) belongs to the OLD last_off, so when the sequence changed it the three loads at
+//     p - last_off are issued again (contiguous: a line or two) and the lane's tests are redone — the only trip a chained sequence
+//     costs.  A repeat-offset match changes nothing and costs none.
+// What a lane found in its slot is exact iff every lane below it on the same slot happened (the replay walks ALL same-slot lanes in
+// lane order = position order = the reference's order).  Lanes inside a match never happen, so a lane of the next stretch — or a
+// lazy lane — with a same-slot lane below it that did not happen is "stale": the chain stops there and the next round starts at
+// that position with a table settled for exactly the lanes that happened (the settle rule needs nothing else: the last committed
+// lane of a slot stores what it left there).  Lengths that do not resolve from the fetched bytes (>= 24 forward, >= 8 backward), a
+// lazy position beyond the round, or a lazy lane whose forward count was taken against its repeat candidate fall back to the
+// memory-based steps below, after which the round is over.
+#ifndef LZ_PF_CHAIN
+#define LZ_PF_CHAIN 1
+#endif
+// backward run of a candidate pair from the 8 bytes fetched behind both (cb equal bytes; nothing fetched: haveBack false, cb 0),
+// limited to roomB: exact, or LZ_PF_UNRESOLVED when it may go on past the fetched bytes.  Wave-uniform.
+LZ_DEV u32 lz_pf_back_from(u32 cb, bool haveBack, u32 roomB)
+{
+    return (roomB <= cb || (haveBack && cb < 8u)) ? (cb < roomB ? cb : roomB) : LZ_PF_UNRESOLVED;
+}
+// A lane's tests from its fetched bytes: the repeat-offset candidate (r*) wins and hides the hash candidate (c*), pricefast.h:19-31;
+// the hash candidate needs the 4-byte test (:67) and, behind a long offset, minMatchLongOff bytes (:69: 16 <= 24 fetched bytes).
+// fwd = forward length against whichever candidate counts, exact when the difference (or the limit) lies inside the fetched bytes.
+LZ_DEV void lz_pf_measure(bool repCand, bool hashCand, u64 bytes, u64 pB, u64 pC, u64 rA, u64 rB, u64 rC, u64 cA, u64 cB, u64 cC,
+                          bool have24, u32 room, u32 dist, bool& rep, bool& hashOk, u32& fwd)
+{
+    const u32 first4 = (u32)bytes;
+    rep = repCand && (u32)rA == first4;
+    const u64 x = bytes ^ (rep ? rA : cA), y = pB ^ (rep ? rB : cB), y2 = pC ^ (rep ? rC : cC);
+    const u32 seen = have24 ? 24u : 16u;
+    const u32 common = x ? lz_ctz64(x) >> 3 : y ? 8u + (lz_ctz64(y) >> 3) : (have24 && y2) ? 16u + (lz_ctz64(y2) >> 3) : seen;
+    fwd = LZ_PF_UNRESOLVED;
+    if (common < seen || room <= seen) fwd = common < room ? common : room;
+    hashOk = !rep && hashCand && (u32)cA == first4
+          && (dist < LZ_16BIT_OFFSET || (have24 && common >= LZ_MM_LONGOFF && room >= LZ_MM_LONGOFF));
+}
+
+#if LZ_PF_CHAIN
+template <int HASHLOG, int TAGLOG, class TAB>
+LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8* tag, LzStreams& st)
+{
+    const u32 lane = lz_lane();
+    const u64 laneBit = 1ull << lane;
+    const u64 lanesBelow = laneBit - 1ull;
+    const u32 maxDist = (1u << 22) - 1u;
+    const u32 tagMask = (1u << TAGLOG) - 1u;
+    u32 anchor = S;                                              // uniform
+    u32 last_off = 0;                                            // uniform; Lizard_initBlock, lizard_compress.c:137
+    if (E - S < LZ_MFLIMIT + 1u) { st.lastLits = E - S; st.nlit += E - S; return; }
+    const u32 mflimit = E - LZ_MFLIMIT, matchlimit = E - LZ_LASTLITERALS;
+    u32 ip = S + 1u;                                             // uniform, pricefast.h:155
+    constexpr bool kNarrow = !TAB::kSpecPut && LZ_PF_W0 < 64u;   // round width over a global-memory table: see the unchained form
+    u32 W = kNarrow ? LZ_PF_W0 : 64u;                            // uniform
+    u32 winBase = ip;                                            // uniform: register window, wA = 8 bytes at winBase + lane, wB = at winBase + 64 + lane
+    u64 wA, wB;
+    { const u32 qa = ip + lane, qb = ip + 64u + lane; wA = lz_ld64(src + (qa < mflimit ? qa : S)); wB = lz_ld64(src + (qb < mflimit ? qb : S)); }
+    for (;;) {
+        // ---------------- one round: 64 consecutive positions ----------------
+        if (ip >= mflimit) goto tail;                            // pricefast.h:158
+        if constexpr (TAB::kSweeps) if (ip >= st.sweepAt) { table.sync(); lz_pf_tab_sweep<HASHLOG>(table, ip); st.sweepAt = ip + LZ_PF_SWEEP_EVERY; table.sync(); }
+        if (ip != winBase) {                                     // move the window (see the unchained form)
+            const u32 d = ip - winBase;                          // uniform
+            const u32 qa = ip + lane, qb = ip + 64u + lane;
+            if (d == 64u) wA = wB;
+            else if (d < 64u) {
+                const u32 sl = (d + lane) & 63u;
+                const u32 al = lz_shfl((u32)wA, sl), ah = lz_shfl((u32)(wA >> 32), sl);
+                const u32 bl = lz_shfl((u32)wB, sl), bh = lz_shfl((u32)(wB >> 32), sl);
+                wA = d + lane < 64u ? ((u64)al | ((u64)ah << 32)) : ((u64)bl | ((u64)bh << 32));
+            }
+            else wA = lz_ld64(src + (qa < mflimit ? qa : S));
+            wB = lz_ld64(src + (qb < mflimit ? qb : S));
+            winBase = ip;
+        }
+        const u32 ip0 = ip;                                      // uniform: lane k of this round is position ip0 + k
+        const u32 p = ip0 + lane;
+        const bool valid = p < mflimit && (!kNarrow || lane < W);
+        const u32 lowPos = p > maxDist ? p - maxDist : 0u;       // pricefast.h:11-13, per probe
+        const u64 bytes = wA;
+        const u32 first4 = (u32)bytes;
+        const u32 h = lz_hash5_plain<HASHLOG>(bytes);
+        const u32 myChk = TAB::chkOf(first4);
+        u32 e, ec;                                               // pricefast.h:160,168 (old value; garbage when !valid); its check bits
+        { const u32 raw = table.get(kNarrow && !valid ? 0u : h, p); e = TAB::pos(raw); ec = TAB::chk(raw); }
+        bool lost;                                               // same-slot lanes of this round (see the unchained form)
+        if constexpr (TAB::kSpecPut) {
+            lz_lds_sync();
+            if (valid) table.specPut(h, p);
+            lz_lds_sync();
+            lost = valid && table.specLost(h, p);
+        } else {
+            if (valid) tag[h & tagMask] = (u8)lane;
+            lz_lds_sync();
+            lost = valid && tag[h & tagMask] != (u8)lane;
+            lz_lds_sync();
+        }
+        LZ_PROF(st, 8);                                          // (instrumented build) round: window, hash, table read
+        const u32 eOld = e, ecOld = ec;
+        u64 pend = lz_ballot(lost);
+        u64 grp = laneBit;
+        const bool putAlone = TAB::age(p, e) - 1u >= LZ_MIN_OFFSET - 1u;     // pricefast.h:170-171 when alone in the slot
+        u32 tAfter = putAlone ? p : e, tcAfter = putAlone ? myChk : ec;
+        while (pend) {                                           // same-slot lanes: replay the puts in lane order
+            const u32 f = lz_ctz64(pend);
+            const u32 hv = lz_readlane(h, f);
+            const bool mine = valid && h == hv;
+            const u64 g = lz_ballot(mine);
+            u32 t = lz_readlane(e, f);
+            u32 tc = lz_readlane(ec, f);
+            for (u64 m = g; m; m &= m - 1ull) {
+                const u32 k = lz_ctz64(m), pk = ip0 + k;
+                const u32 ck = lz_readlane(myChk, k);
+                if (lane == k) { e = t; ec = tc; }
+                const bool put = TAB::age(pk, t) - 1u >= LZ_MIN_OFFSET - 1u;
+                t = put ? TAB::pos(TAB::make(pk, 0u)) : t; tc = put ? ck : tc;
+                if (lane == k) { tAfter = t; tcAfter = tc; }
+            }
+            if (mine) grp = g;
+            pend &= ~g;
+        }
+        LZ_PROF(st, 9);                                          // round: same-slot replay
+        // candidates (Lizard_FindMatchFast, pricefast.h:3-87) and one batch of loads for both kinds
+        const u32 ageE = TAB::age(p, e);
+        const bool hashCand = valid && ageE >= LZ_MIN_OFFSET && ageE <= (p > maxDist ? maxDist : p) && ec == myChk;   // :63-65 + check bits
+        e = p - ageE;                                            // the candidate's position in the block (hashCand lanes)
+        const bool have24 = p + 24u <= E;
+        const u32 fc = have24 ? 16u : 0u;
+        const u32 pp = valid ? p : S;
+        const u32 room = matchlimit - p;                         // p < matchlimit for every valid slot
+        const u64 pB = lz_ld64(src + pp + 8u), pC = lz_ld64(src + pp + fc);
+        u64 rA, rB, rC;
+        {
+            const bool repCand = valid && last_off >= LZ_MIN_OFFSET && p >= last_off && p - last_off >= lowPos;   // :19
+            const u32 rp = repCand ? p - last_off : S;
+            rA = lz_ld64(src + rp); rB = lz_ld64(src + rp + 8u); rC = lz_ld64(src + rp + fc);
+        }
+        u64 cA = 0, cB = 0, cC = 0, cZ = 0, pZ = 0;
+        const bool haveBack = hashCand && e >= 8u;               // then p >= 16 as well
+        if (hashCand) {                                          // one batch, straight-line
+            const u32 zb = haveBack ? 8u : 0u;
+            cA = lz_ld64(src + e); cB = lz_ld64(src + e + 8u); cC = lz_ld64(src + e + fc);
+            cZ = lz_ld64(src + (e - zb)); pZ = lz_ld64(src + (p - zb));
+        }
+        lz_converge();
+        bool rep, hashOk;
+        u32 fwd;
+        lz_pf_measure(valid && last_off >= LZ_MIN_OFFSET && p >= last_off && p - last_off >= lowPos, hashCand, bytes, pB, pC, rA, rB, rC,
+                      cA, cB, cC, have24, room, p - e, rep, hashOk, fwd);
+        u32 cb;                                                  // equal bytes in the 8 behind position and hash candidate
+        { const u64 z = pZ ^ cZ; cb = !haveBack ? 0u : z ? lz_clz64(z) >> 3 : 8u; }
+        lz_pin(fwd); lz_pin(cb);                                 // computed here, under this batch's counted wait
+        u64 okMask = lz_ballot(rep || hashOk);
+        u64 repMask = lz_ballot(rep);
+        const u64 validMask = lz_ballot(valid);                  // a prefix of lanes
+        const u64 hashCandMask = lz_ballot(hashCand), haveBackMask = lz_ballot(haveBack);
+        LZ_PROF(st, 10);                                         // round: candidate bytes, tests
+
+        // ---------------- the sequences of this round ----------------
+        u64 commit = 0;                                          // uniform: lanes whose probe + put happened
+        u32 c = 0;                                               // uniform: first lane of the stretch being searched
+        u32 slow = 0;                                            // uniform: 1 = winner lengths from memory, 2 = lazy step from memory
+        u32 P = 0, M = 0, ml = 0, back0 = 0;
+        u32 ml2 = 0, start2 = 0, ref2 = 0, ref = 0, back2 = 0;
+        u32 measuredOff = last_off;                              // the last_off the lanes' repeat tests belong to
+        for (;;) {
+            const u64 seg = ~0ull << c;
+            const u64 ok2 = okMask & seg;
+            const u32 w = ok2 ? lz_ctz64(ok2) : 63u;
+            const u64 readers = validMask & seg & (~0ull >> (63u - w));     // the probes up to the winner: all of them happen
+            if (c) {
+                const bool staleLane = (grp & lanesBelow & ~(commit | readers)) != 0;
+                if (lz_ballot(staleLane) & readers) { LZ_STAT(32); ip = ip0 + c; if constexpr (kNarrow) W = LZ_PF_W0; break; }
+            }
+            commit |= readers;
+            if (!ok2) {                                          // "ip++" for every probed position, :173
+                if (c) LZ_STAT(33);
+                ip = ip0 + lz_popc64(validMask);
+                if constexpr (kNarrow) { if (c) W = LZ_PF_W0; W = W < 32u ? 2u * W : 64u; }
+                break;
+            }
+            if constexpr (kNarrow) W = LZ_PF_W0;
+            // ---- winner: lane w ----
+            P = lz_readlane(p, w);
+            M = ((repMask >> w) & 1ull) ? P - last_off : lz_readlane(e, w);
+            ml = lz_readlane(fwd, w);
+            ip = P; ref = M;
+            const bool repMatch = ip - ref == last_off;          // :174 -> repeat offset: no backward extension, no lazy step
+            back0 = repMatch ? 0u : lz_pf_back_from(lz_readlane(cb, w), (haveBackMask >> w) & 1ull, (P - anchor) < M ? (P - anchor) : M);   // :176-180
+            if (ml == LZ_PF_UNRESOLVED || back0 == LZ_PF_UNRESOLVED) { LZ_STAT(34); slow = 1u; break; }
+            if (c) { LZ_STAT(35); if (repMatch) LZ_STAT(36); }   // a winner found in a later stretch of the round
+            if (repMatch) ref = ip;
+            else { ip -= back0; ref -= back0; ml += back0; }    // :176-182
+            bool lazy = !repMatch;
+            for (;;) {                                           // this winner's sequence, and the second match's when one is kept (:233-238)
+                ml2 = 0;
+                while (lazy) {                                   // "search:", :184-228
+                    if (ip + ml >= mflimit) break;               // :185
+                    start2 = ip + ml - 2u;
+                    const u32 ls = start2 - ip0;                 // its lane (above every lane that happened so far)
+                    if (ls > 63u || !((validMask >> ls) & 1ull)) { LZ_STAT(37); slow = 2u; break; }
+                    const u64 staleMask = lz_ballot((grp & lanesBelow & ~commit) != 0);
+                    if (((staleMask | repMask) >> ls) & 1ull) { LZ_STAT(38); slow = 2u; break; }      // (repMask: its fwd belongs to the repeat candidate)
+                    u32 mlt = 0, e2 = 0, b2 = 0;
+                    bool found = false;
+                    if ((hashCandMask >> ls) & 1ull) {           // :106-110 (check bits differ: :109 fails)
+                        mlt = lz_readlane(fwd, ls);
+                        if (mlt == LZ_PF_UNRESOLVED) { LZ_STAT(39); slow = 2u; break; }
+                        e2 = lz_readlane(e, ls);
+                        if (mlt >= 4u && (mlt >= LZ_MM_LONGOFF || start2 - e2 < LZ_16BIT_OFFSET)) {     // :109 4 bytes (room >= 5 here), :112
+                            b2 = lz_pf_back_from(lz_readlane(cb, ls), (haveBackMask >> ls) & 1ull, (start2 - ip) < e2 ? (start2 - ip) : e2);   // :195-201
+                            if (b2 == LZ_PF_UNRESOLVED) { LZ_STAT(40); slow = 2u; break; }
+                            found = true;
+                        }
+                    }
+                    commit |= 1ull << ls;                        // :190-191: the lane's own (conditional) put
+                    LZ_STAT(41);
+                    if (!found) break;
+                    LZ_STAT(42);
+                    ml2 = mlt + b2; ref2 = e2 - b2; start2 -= b2;                                  // :195-201
+                    if (ml2 <= ml) { LZ_STAT(43); ml2 = 0; break; }                                 // :203
+                    if (start2 <= ip) { LZ_STAT(44); ip = start2; ref = ref2; ml = ml2; ml2 = 0; break; }        // :205-210
+                    if (start2 - ip < 3u) { LZ_STAT(45); ip = start2; ref = ref2; ml = ml2; ml2 = 0; continue; } // :212-217
+                    if (start2 < ip + ml) {                                                         // :219-228
+                        const u32 correction = ml - (start2 - ip);
+                        LZ_STAT(46);
+                        start2 += correction; ref2 += correction; ml2 -= correction;
+                        if (ml2 < 3u) ml2 = 0;
+                        if (ml2 < LZ_MM_LONGOFF && start2 - ref2 >= LZ_16BIT_OFFSET) ml2 = 0;
+                    }
+                    if (ml2) LZ_STAT(47);
+                    break;
+                }
+                if (slow) break;
+                {
+                    const u32 off = ip - ref;                    // 0 = repeat (ref == ip), liz.h:122
+                    lz_seq_push_liz(st, ip - anchor, ml, off);   // :231 (encoded later, in parallel)
+                    if (off != 0u) last_off = off;               // liz.h:119,135
+                }
+                ip += ml; anchor = ip;
+                LZ_STAT(48);                                     // a sequence pushed from registers
+                if (!ml2) break;
+                LZ_STAT(49);
+                ip = start2; ref = ref2; ml = ml2; lazy = true;  // :233-238
+            }
+            if (slow) break;
+            LZ_PROF(st, 2);                                      // winner lengths / arbitration / push from registers
+            // ---- the next search starts at ip: the lanes from ip - ip0 on ----
+            c = ip - ip0;
+            if (c > 63u || !((validMask >> c) & 1ull)) break;    // beyond the round (or its width, or mflimit): the next round starts at ip
+            if constexpr (TAB::kSweeps) if (ip >= st.sweepAt) break;
+            if (last_off != measuredOff) {                       // their repeat-offset side again (:19-31), one trip
+                LZ_STAT(50);
+                const bool repCand = valid && lane >= c && last_off >= LZ_MIN_OFFSET && p >= last_off && p - last_off >= lowPos;
+                const u32 rp = repCand ? p - last_off : S;
+                rA = lz_ld64(src + rp); rB = lz_ld64(src + rp + 8u); rC = lz_ld64(src + rp + fc);
+                lz_converge();
+                lz_pf_measure(repCand, hashCand, bytes, pB, pC, rA, rB, rC, cA, cB, cC, have24, room, p - e, rep, hashOk, fwd);
+                lz_pin(fwd);
+                okMask = lz_ballot(rep || hashOk);
+                repMask = lz_ballot(rep);
+                measuredOff = last_off;
+                LZ_PROF(st, 1);
+            }
+        }
+        // settle the table for exactly the lanes that happened
+        if constexpr (TAB::kSpecPut) {
+            // the last committed lane of every slot group stores the slot's final value; a group none of whose lanes happened is
+            // restored by its first lane (whose eOld is the value from before the round)
+            const u64 cm = grp & commit;
+            const bool writer = valid && (cm ? (cm >> lane) == 1ull : (grp & lanesBelow) == 0);
+            if (writer) table.set(h, cm ? TAB::make(tAfter, tcAfter) : TAB::make(eOld, ecOld));
+        } else {
+            if ((commit & laneBit) && (grp & commit & ~(lanesBelow | laneBit)) == 0) table.set(h, TAB::make(tAfter, tcAfter));
+        }
+        table.sync();
+        LZ_PROF(st, 11);                                         // round: table put
+        if (!slow) continue;
+
+        // ---------------- the steps that need memory (then the round is over) ----------------
+        LZ_PROF(st, 0);
+        {
+            if (slow == 2u) goto search;
+            if (ml == LZ_PF_UNRESOLVED) ml = 24u + lz_count_fwd(src, P + 24u, M + 24u, matchlimit);   // (unresolved: 24 bytes were seen and agree)
+            ref = M;
+            ip = P;
+            if (ip - ref == last_off) { ref = ip; goto encode; }                          // :174
+            if (back0 == LZ_PF_UNRESOLVED) back0 = lz_count_back(src, P, M, anchor);
+            ip -= back0; ref -= back0; ml += back0;                                       // :176-182
+        search:
+            LZ_PROF(st, 2);
+            ml2 = 0;
+            if (ip + ml >= mflimit) goto encode;                                          // :185
+            start2 = ip + ml - 2u;
+            {
+                const u32 i2 = start2 - winBase;                 // uniform: the 8 bytes at start2 out of the register window when it reaches
+                u64 b2;
+                if (i2 < 128u) {
+                    const u32 lo = i2 < 64u ? lz_readlane((u32)wA, i2 & 63u) : lz_readlane((u32)wB, i2 & 63u);
+                    const u32 hi = i2 < 64u ? lz_readlane((u32)(wA >> 32), i2 & 63u) : lz_readlane((u32)(wB >> 32), i2 & 63u);
+                    b2 = (u64)lo | ((u64)hi << 32);
+                } else b2 = lz_ld64(src + start2);
+                const u32 h2 = lz_hash5_plain<HASHLOG>(b2);
+                const u32 raw2 = table.get(h2, start2);
+                const u32 c2 = TAB::chk(raw2), chk2 = TAB::chkOf((u32)b2);
+                const u32 age2 = TAB::age(start2, TAB::pos(raw2)), e2 = start2 - age2;
+                ml2 = 0; back2 = 0;
+                if (age2 >= LZ_MIN_OFFSET && age2 <= (start2 > maxDist ? maxDist : start2) && c2 == chk2) {   // :106-110
+                    u32 mlt;
+                    lz_count_both(src, start2, e2, matchlimit, ip, mlt, back2);
+                    if (mlt >= 4u && (mlt >= LZ_MM_LONGOFF || start2 - e2 < LZ_16BIT_OFFSET)) { ml2 = mlt; ref2 = e2; }   // :112
+                }
+                table.sync();
+                if (lane == 0 && age2 - 1u >= LZ_MIN_OFFSET - 1u) table.set(h2, TAB::make(start2, chk2));   // :190-191
+                table.sync();
+            }
+            LZ_PROF(st, 1);
+            if (!ml2) goto encode;
+            start2 -= back2; ref2 -= back2; ml2 += back2;                                 // :195-201
+            if (ml2 <= ml) { ml2 = 0; goto encode; }                                      // :203
+            if (start2 <= ip) { ip = start2; ref = ref2; ml = ml2; ml2 = 0; goto encode; }            // :205-210
+            if (start2 - ip < 3u) { ip = start2; ref = ref2; ml = ml2; ml2 = 0; goto search; }        // :212-217
+            if (start2 < ip + ml) {                                                       // :219-228
+                const u32 correction = ml - (start2 - ip);
+                start2 += correction; ref2 += correction; ml2 -= correction;
+                if (ml2 < 3u) ml2 = 0;
+                if (ml2 < LZ_MM_LONGOFF && start2 - ref2 >= LZ_16BIT_OFFSET) ml2 = 0;
+            }
+        encode:
+            LZ_PROF(st, 2);
+            {
+                const u32 off = ip - ref;
+                lz_seq_push_liz(st, ip - anchor, ml, off);
+                if (off != 0u) last_off = off;
+            }
+            LZ_STAT(51);                                         // a sequence pushed by the memory-based steps
+            LZ_PROF(st, 3);
+            ip += ml; anchor = ip;
+            if (ml2) { ip = start2; ref = ref2; ml = ml2; ml2 = 0; goto search; }         // :233-238
+        }
+    }
+tail:
+    if (st.nseq & (LZ_SEQ_RING - 1u)) lz_seq_flush(st);
+    st.lastLits = E - anchor; st.nlit += E - anchor;             // liz.h:168-179
+}
+#else    // LZ_PF_CHAIN == 0: one sequence per round, lazy step from memory (rounds 2-3; A/B builds)
 template <int HASHLOG, int TAGLOG, class TAB>
 LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8* tag, LzStreams& st)
 {
@@ -455,3 +807,4 @@ tail:
     if (st.nseq & (LZ_SEQ_RING - 1u)) lz_seq_flush(st);
     st.lastLits = E - anchor; st.nlit += E - anchor;             // liz.h:168-179
 }
+#endif   // LZ_PF_CHAIN

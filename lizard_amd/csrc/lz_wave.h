@@ -107,6 +107,7 @@ LZ_DEV void lz_table_sync()
 // later conditional block).  Used to keep arithmetic on just-loaded data next to the counted
 // s_waitcnt of its own load batch instead of behind a later, conservative vmcnt(0).
 LZ_DEV void lz_pin(u32& x) { asm volatile("" : "+v"(x)); }
+#define LZ_STAT(i) ((void)0)                                   /* event counters exist in the test emulator only (tests/emul/lz_wave.h) */
 // product of two values below 2^24: one full-rate v_mul_u32_u24 (v_mul_lo_u32 is a quarter-rate instruction)
 LZ_DEV u32 lz_mul24(u32 a, u32 b) { return (u32)__umul24(a, b); }
 // keeps the optimiser from folding a cheap form back into the expensive one it was written to avoid

@@ -23,6 +23,13 @@ void entry_block(void* a)
 
 
 
+unsigned long long lzemu_stats[64];
+// event counters of the kernels' LZ_STAT marks since the last reset
+extern "C" void emul_stats(unsigned long long* out, int reset)
+{
+    for (int i = 0; i < 64; i++) { out[i] = __atomic_load_n(&lzemu_stats[i], __ATOMIC_RELAXED); if (reset) __atomic_store_n(&lzemu_stats[i], 0ull, __ATOMIC_RELAXED); }
+}
+
 // hashChain levels keep one persistent global slot that is never cleared (as the host library does): whatever an earlier
 // block left in it (bins, links, saved head tables) must not matter.
 static u8* g_hcSlot = nullptr;

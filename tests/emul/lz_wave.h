@@ -117,6 +117,9 @@ LZ_DEV void lz_wave_sync() { lzemu::park(lzemu::OP_SYNC); }
 LZ_DEV void lz_lds_sync() { lzemu::park(lzemu::OP_SYNC); }
 LZ_DEV void lz_table_sync() { lzemu::park(lzemu::OP_SYNC); }
 LZ_DEV void lz_pin(u32& x) { (void)x; }
+// event counters (coverage of the parsers' paths under test): LZ_STAT(i) counts once per wave; read with emul_stats()
+extern "C" unsigned long long lzemu_stats[64];
+#define LZ_STAT(i) do { if (lz_lane() == 0) __atomic_add_fetch(&lzemu_stats[i], 1ull, __ATOMIC_RELAXED); } while (0)
 LZ_DEV u32 lz_mul24(u32 a, u32 b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 LZ_DEV u32 lz_opaque(u32 x) { return x; }
 LZ_DEV u32 lz_mulhi(u32 a, u32 b) { return (u32)(((u64)a * b) >> 32); }
