@@ -228,9 +228,11 @@ LZ_DEV void lz_encode_lizv1(const u8* src, u32 S, const LzStreams& st, u8* litOu
 // (lizard_common.h:249-250).  table: 2^HASHLOG slots (TAB::kEmpty = never written); tag: 2^TAGLOG bytes of LDS (global tables only).
 // Positions must stay below TAB::kEmpty (the launcher picks the table form by block size).
 #define LZ_PF_UNRESOLVED 0xFFFFu
+#define LZ_PF_UNRESOLVED4 0xFFFEu    // only the 4-byte test is known to hold (a repeat-offset candidate tested again inside a round)
 #ifndef LZ_PF_W0
-#define LZ_PF_W0 32u
-#endif
+#define LZ_PF_W0 64u                  // round width over a global-memory table right after a match.  Rounds 3: 32 (the lanes behind a
+#endif                                // winner were probed for nothing, +2.8 %); with several sequences per round those lanes are the next
+                                      // stretch: 64 is +3.7 % at level 21, +2.6 % at 41, +5.8 % on 4 MiB blocks (profiles/r04u_*)
 // ---- several sequences out of one round (round 4) ----
 // A round has paid for 64 consecutive positions: every lane holds its slot's value as the reference's serial walk would have found
 // it (the same-slot replay), its hash candidate's bytes and its repeat-offset test.  The reference's next steps behind a winner are
@@ -313,6 +315,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
             winBase = ip;
         }
         const u32 ip0 = ip;                                      // uniform: lane k of this round is position ip0 + k
+        LZ_STAT(55);
         const u32 p = ip0 + lane;
         const bool valid = p < mflimit && (!kNarrow || lane < W);
         const u32 lowPos = p > maxDist ? p - maxDist : 0u;       // pricefast.h:11-13, per probe
@@ -337,6 +340,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
         LZ_PROF(st, 8);                                          // (instrumented build) round: window, hash, table read
         const u32 eOld = e, ecOld = ec;
         u64 pend = lz_ballot(lost);
+        const bool anyGroups = pend != 0;                        // uniform: some lanes of this round share a slot
         u64 grp = laneBit;
         const bool putAlone = TAB::age(p, e) - 1u >= LZ_MIN_OFFSET - 1u;     // pricefast.h:170-171 when alone in the slot
         u32 tAfter = putAlone ? p : e, tcAfter = putAlone ? myChk : ec;
@@ -386,13 +390,20 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
         u32 fwd;
         lz_pf_measure(valid && last_off >= LZ_MIN_OFFSET && p >= last_off && p - last_off >= lowPos, hashCand, bytes, pB, pC, rA, rB, rC,
                       cA, cB, cC, have24, room, p - e, rep, hashOk, fwd);
-        u32 cb;                                                  // equal bytes in the 8 behind position and hash candidate
-        { const u64 z = pZ ^ cZ; cb = !haveBack ? 0u : z ? lz_clz64(z) >> 3 : 8u; }
+        u32 cb;                                                  // equal bytes in the 8 behind position and hash candidate (+ 16: something was fetched)
+        { const u64 z = pZ ^ cZ; cb = !haveBack ? 0u : 16u + (z ? lz_clz64(z) >> 3 : 8u); }
         lz_pin(fwd); lz_pin(cb);                                 // computed here, under this batch's counted wait
+        // What the scalar steps below read from a lane, packed so that one v_readlane brings all of it:
+        //   hinfo  the hash side, which does not depend on last_off: forward length against the hash candidate (16 bits) | cb << 16 |
+        //          hashCand << 21 | "known" << 22 (a lane whose forward count was taken against its repeat candidate has no hash side
+        //          yet) | "passes when no repeat candidate hides it" << 23
+        //   winfo  the side that counts if the lane wins: forward length | cb << 16 | "repeat candidate" << 21
+        // A changed last_off only needs the 4-byte repeat test again: winfo is rebuilt from hinfo.
+        bool hashKnown = !rep || !hashCand;
+        u32 hinfo = fwd | (cb << 16) | ((u32)hashCand << 21) | ((u32)hashKnown << 22) | ((u32)hashOk << 23);
+        u32 winfo = fwd | (cb << 16) | ((u32)rep << 21);
         u64 okMask = lz_ballot(rep || hashOk);
-        u64 repMask = lz_ballot(rep);
         const u64 validMask = lz_ballot(valid);                  // a prefix of lanes
-        const u64 hashCandMask = lz_ballot(hashCand), haveBackMask = lz_ballot(haveBack);
         LZ_PROF(st, 10);                                         // round: candidate bytes, tests
 
         // ---------------- the sequences of this round ----------------
@@ -407,7 +418,10 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
             const u64 ok2 = okMask & seg;
             const u32 w = ok2 ? lz_ctz64(ok2) : 63u;
             const u64 readers = validMask & seg & (~0ull >> (63u - w));     // the probes up to the winner: all of them happen
-            if (c) {
+            if (c && anyGroups) {
+                // (Working a stale lane's view out again from the lanes that did happen does not pay: same-slot lanes of one round
+                //  are repeats of the same bytes, so 9 times out of 10 the corrected value IS a candidate — whose bytes were never
+                //  requested.  Measured under emulation, round 4.)
                 const bool staleLane = (grp & lanesBelow & ~(commit | readers)) != 0;
                 if (lz_ballot(staleLane) & readers) { LZ_STAT(32); ip = ip0 + c; if constexpr (kNarrow) W = LZ_PF_W0; break; }
             }
@@ -420,14 +434,15 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
             }
             if constexpr (kNarrow) W = LZ_PF_W0;
             // ---- winner: lane w ----
-            P = lz_readlane(p, w);
-            M = ((repMask >> w) & 1ull) ? P - last_off : lz_readlane(e, w);
-            ml = lz_readlane(fwd, w);
+            const u32 wi = lz_readlane(winfo, w);
+            P = ip0 + w;
+            M = ((wi >> 21) & 1u) ? P - last_off : lz_readlane(e, w);
+            ml = wi & 0xFFFFu;
             ip = P; ref = M;
             const bool repMatch = ip - ref == last_off;          // :174 -> repeat offset: no backward extension, no lazy step
-            back0 = repMatch ? 0u : lz_pf_back_from(lz_readlane(cb, w), (haveBackMask >> w) & 1ull, (P - anchor) < M ? (P - anchor) : M);   // :176-180
-            if (ml == LZ_PF_UNRESOLVED || back0 == LZ_PF_UNRESOLVED) { LZ_STAT(34); slow = 1u; break; }
-            if (c) { LZ_STAT(35); if (repMatch) LZ_STAT(36); }   // a winner found in a later stretch of the round
+            { const u32 cbw = (wi >> 16) & 31u; back0 = repMatch ? 0u : lz_pf_back_from(cbw & 15u, cbw >= 16u, (P - anchor) < M ? (P - anchor) : M); }   // :176-180
+            if (ml >= LZ_PF_UNRESOLVED4 || back0 == LZ_PF_UNRESOLVED) { LZ_STAT(34); slow = 1u; break; }
+            if (c) LZ_STAT(35);                                  // a winner found in a later stretch of the round
             if (repMatch) ref = ip;
             else { ip -= back0; ref -= back0; ml += back0; }    // :176-182
             bool lazy = !repMatch;
@@ -438,16 +453,17 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
                     start2 = ip + ml - 2u;
                     const u32 ls = start2 - ip0;                 // its lane (above every lane that happened so far)
                     if (ls > 63u || !((validMask >> ls) & 1ull)) { LZ_STAT(37); slow = 2u; break; }
-                    const u64 staleMask = lz_ballot((grp & lanesBelow & ~commit) != 0);
-                    if (((staleMask | repMask) >> ls) & 1ull) { LZ_STAT(38); slow = 2u; break; }      // (repMask: its fwd belongs to the repeat candidate)
+                    const u32 hi = lz_readlane(hinfo, ls);
+                    if (!((hi >> 22) & 1u)) { LZ_STAT(38); slow = 2u; break; }                        // its forward count belongs to a repeat candidate
+                    if (anyGroups && (lz_readlane64(grp, ls) & ((1ull << ls) - 1ull) & ~commit) != 0) { LZ_STAT(52); slow = 2u; break; }   // stale: see above
                     u32 mlt = 0, e2 = 0, b2 = 0;
                     bool found = false;
-                    if ((hashCandMask >> ls) & 1ull) {           // :106-110 (check bits differ: :109 fails)
-                        mlt = lz_readlane(fwd, ls);
+                    if ((hi >> 21) & 1u) {                       // :106-110 (check bits differ: :109 fails)
+                        mlt = hi & 0xFFFFu;
                         if (mlt == LZ_PF_UNRESOLVED) { LZ_STAT(39); slow = 2u; break; }
                         e2 = lz_readlane(e, ls);
                         if (mlt >= 4u && (mlt >= LZ_MM_LONGOFF || start2 - e2 < LZ_16BIT_OFFSET)) {     // :109 4 bytes (room >= 5 here), :112
-                            b2 = lz_pf_back_from(lz_readlane(cb, ls), (haveBackMask >> ls) & 1ull, (start2 - ip) < e2 ? (start2 - ip) : e2);   // :195-201
+                            { const u32 cbl = (hi >> 16) & 31u; b2 = lz_pf_back_from(cbl & 15u, cbl >= 16u, (start2 - ip) < e2 ? (start2 - ip) : e2); }   // :195-201
                             if (b2 == LZ_PF_UNRESOLVED) { LZ_STAT(40); slow = 2u; break; }
                             found = true;
                         }
@@ -488,16 +504,20 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
             c = ip - ip0;
             if (c > 63u || !((validMask >> c) & 1ull)) break;    // beyond the round (or its width, or mflimit): the next round starts at ip
             if constexpr (TAB::kSweeps) if (ip >= st.sweepAt) break;
-            if (last_off != measuredOff) {                       // their repeat-offset side again (:19-31), one trip
+            if (last_off != measuredOff) {                       // their repeat-offset side again (:19-31): the 4-byte test decides
                 LZ_STAT(50);
                 const bool repCand = valid && lane >= c && last_off >= LZ_MIN_OFFSET && p >= last_off && p - last_off >= lowPos;
-                const u32 rp = repCand ? p - last_off : S;
-                rA = lz_ld64(src + rp); rB = lz_ld64(src + rp + 8u); rC = lz_ld64(src + rp + fc);
-                lz_converge();
-                lz_pf_measure(repCand, hashCand, bytes, pB, pC, rA, rB, rC, cA, cB, cC, have24, room, p - e, rep, hashOk, fwd);
-                lz_pin(fwd);
-                okMask = lz_ballot(rep || hashOk);
-                repMask = lz_ballot(rep);
+                const u64 rN = lz_ld64(src + (repCand ? p - last_off : S));
+                rep = repCand && (u32)rN == first4;
+                const bool needHash = !rep && hashCand && lane >= c && !hashKnown;
+                if (lz_ballot(needHash)) {                       // (rare) the hash side of lanes that had a repeat match when the round was measured
+                    bool r0, h0; u32 f0;
+                    LZ_STAT(54);
+                    lz_pf_measure(false, hashCand, bytes, pB, pC, 0, 0, 0, cA, cB, cC, have24, room, p - e, r0, h0, f0);
+                    if (needHash) { hashKnown = true; hinfo = f0 | (cb << 16) | (1u << 21) | (1u << 22) | ((u32)h0 << 23); }
+                }
+                winfo = rep ? (LZ_PF_UNRESOLVED4 | (cb << 16) | (1u << 21)) : (hinfo & 0x1FFFFFu);
+                okMask = lz_ballot(rep || (hinfo >> 22) == 3u);  // known and passing
                 measuredOff = last_off;
                 LZ_PROF(st, 1);
             }
@@ -521,6 +541,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
         {
             if (slow == 2u) goto search;
             if (ml == LZ_PF_UNRESOLVED) ml = 24u + lz_count_fwd(src, P + 24u, M + 24u, matchlimit);   // (unresolved: 24 bytes were seen and agree)
+            else if (ml == LZ_PF_UNRESOLVED4) ml = 4u + lz_count_fwd(src, P + 4u, M + 4u, matchlimit);
             ref = M;
             ip = P;
             if (ip - ref == last_off) { ref = ip; goto encode; }                          // :174

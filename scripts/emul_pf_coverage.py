@@ -18,10 +18,10 @@ from test_emulator import emul_compress                  # noqa: E402
 from test_random_parity import make_case, make_long_case # noqa: E402
 
 NAMES = {32: "chain stopped: stale lane in the next stretch", 33: "later stretch without a winner", 34: "winner lengths from memory",
-         35: "winner in a later stretch", 36: "... a repeat-offset match", 37: "lazy position outside the round", 38: "lazy lane stale / repeat-measured",
+         35: "winner in a later stretch", 36: "... a repeat-offset match", 37: "lazy position outside the round", 38: "lazy lane repeat-measured",
          39: "lazy forward count unresolved", 40: "lazy backward count unresolved", 41: "lazy step from registers", 42: "... found a match",
          43: "  ml2 <= ml", 44: "  start2 <= ip (replaces)", 45: "  start2 - ip < 3 (replaces, again)", 46: "  overlap trimmed", 47: "  second match kept",
-         48: "sequence pushed from registers", 49: "second match becomes current", 50: "repeat side fetched again", 51: "sequence pushed by memory steps"}
+         48: "sequence pushed from registers", 49: "second match becomes current", 50: "repeat side tested again", 51: "sequence pushed by memory steps", 52: "lazy lane stale", 54: "... hash side of repeat-measured lanes computed", 55: "rounds"}
 
 
 def stats(reset=True):

@@ -3,9 +3,9 @@ SIMT emulator (tests/emul) and checks them bit-exact against the oracle and the 
 This is how kernel logic is debugged without a GPU; the GPU parity tests (-m gpu) repeat the same
 comparisons through the C ABI on real hardware."""
 import ctypes
-import random
 import json
 import os
+import random
 
 import pytest
 
@@ -243,6 +243,33 @@ def test_emulated_hashchain_block_above_4mib():
     """hashChain keeps full positions (bins are segment-relative, heads and links absolute / distances): a 6 MiB block."""
     data = util.datagen(6 << 20, 0.5, 0.0, 3)
     assert emul_compress(data, 13, 1) == util.oracle_compress(data, 13)
+
+
+def test_emulated_pricefast_chained_paths_are_reached():
+    """Levels 21 / 41 / 22 take several sequences out of one round and run the lazy step (pricefast.h:184-228) from the lanes'
+    registers (lz_pricefast.h, "several sequences out of one round").  The emulator counts the parser's LZ_STAT marks: every exit
+    of the arbitration, every fall-back to the memory-based steps and the stale-lane stop must be reached by this set of inputs —
+    with every output equal to the oracle's — so that the CPU suite really covers them (scripts/emul_pf_coverage.py prints the
+    same counters for a soak)."""
+    E = util.emulator()
+    out = (ctypes.c_ulonglong * 64)()
+    E.emul_stats(out, 1)
+    rnd = random.Random(4)
+    inputs = [util.datagen(150000, 0.5, 0.0, 7), util.datagen(90000, 0.2, 0.0, 8), util.datagen(90000, 0.8, 0.0, 9),
+              (b"the quick brown fox jumps over the lazy dog. " * 2000)[:70000],
+              bytes(rnd.choice(b"ab") for _ in range(30000)) + (b"abcabcabd" * 3000) + bytes(20000)]
+    for i, data in enumerate(inputs):
+        for level, seed in ((21, 1), (21, 2), (21, 4), (41, 2), (22, 1 + i % 2)):       # global-memory table, 18 + 6 bit LDS table, u32 LDS table
+            assert emul_compress(data, level, seed) == util.oracle_compress(data, level), (i, level, seed)
+    E.emul_stats(out, 1)
+    names = {32: "stale lane stops the chain", 33: "later stretch without a winner", 34: "winner lengths from memory", 35: "winner in a later stretch",
+             37: "lazy position outside the round", 38: "lazy lane measured against its repeat candidate", 39: "lazy forward count unresolved",
+             40: "lazy backward count unresolved", 41: "lazy step from registers", 42: "lazy step finds a match", 43: "ml2 <= ml", 44: "start2 <= ip",
+             45: "start2 - ip < 3", 46: "overlap trimmed", 47: "second match kept", 48: "sequence pushed from registers", 49: "second match becomes current",
+             50: "repeat side tested again", 51: "sequence pushed by the memory steps", 52: "lazy lane stale", 54: "hash side computed late", 55: "rounds"}
+    missing = [v for k, v in names.items() if out[k] == 0]
+    assert not missing, missing
+    assert out[48] > 2 * out[51] and out[55] < out[48] + out[51]            # most sequences come from registers; more than one per round
 
 
 def test_emulated_chained_rounds_on_generator_data():
