@@ -314,6 +314,14 @@ float LizardGPU_lastKernelMs(void);
 /* Number of resident waves (= blocks compressed concurrently) the launcher uses on this device. */
 int LizardGPU_residentWaves(void);
 
+/* Launches on different streams.  A launch needs a scratch arena (2.6 GiB), a block counter and — levels 11/31, 21/41, 22/42 —
+ * per-wave tables to itself.  Launches that fill the machine, the hashChain levels and decompression share the context's own and
+ * run one after the other (the second waits on the device for the first); a compress launch SMALLER than the machine that arrives
+ * on another stream while that arena is busy gets one of up to three more, allocated on first need, and runs beside it on the CUs
+ * it leaves free.  LIZARDGPU_ARENAS=1..4 caps the total (default 4; 1 = every launch waits for the previous one).
+ * Returns how many exist right now on the selected device (>= 1 once it was used; 0 before / without a device). */
+int LizardGPU_arenasInUse(void);
+
 /* The one-block entry points of part 1 (Lizard_compress, _extState, _continue) are COMBINED: callers that arrive while a launch is
  * in flight leave together in the next one — one ragged batch, one block per CU — instead of queueing behind a lock, so N host
  * threads compress N blocks per launch (lizard_amd/csrc/lizard_pipeline_host.c).  Launches made / blocks carried so far on the

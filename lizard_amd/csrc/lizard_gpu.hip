@@ -107,6 +107,8 @@ int ctx_init(Ctx& c)
     LZ_HIP(hipMalloc((void**)&c.counter, 64));
     LZ_HIP(hipEventCreate(&c.ev0));
     LZ_HIP(hipEventCreate(&c.ev1));
+    c.nExtra = 0; c.nextExtra = 0; c.maxArenas = LZ_ARENAS_MAX; c.lastStream = nullptr; c.lastEv0 = c.ev0; c.lastEv1 = c.ev1;
+    if (const char* e = getenv("LIZARDGPU_ARENAS")) { const int n = atoi(e); if (n >= 1 && n <= LZ_ARENAS_MAX) c.maxArenas = n; }
     for (Stage& s : c.stage) {
         LZ_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         LZ_HIP(hipEventCreate(&s.k0)); LZ_HIP(hipEventCreate(&s.k1));
@@ -157,6 +159,17 @@ void ctx_release(Ctx& c)
         memset(&s, 0, sizeof s);
     }
     lzk_combiner_free(&c);
+    for (int i = 0; i < c.nExtra; i++) {
+        LzArena& x = c.extra[i];
+        if (x.scratch) (void)hipFree(x.scratch);
+        if (x.counter) (void)hipFree(x.counter);
+        if (x.tables) (void)hipFree(x.tables);
+        if (x.pfTables) (void)hipFree(x.pfTables);
+        if (x.ev0) (void)hipEventDestroy(x.ev0);
+        if (x.ev1) (void)hipEventDestroy(x.ev1);
+        memset(&x, 0, sizeof x);
+    }
+    c.nExtra = 0;
     if (c.tables) (void)hipFree(c.tables);
     if (c.pfTables) (void)hipFree(c.pfTables);
     if (c.hcSlots) (void)hipFree(c.hcSlots);
@@ -166,7 +179,7 @@ void ctx_release(Ctx& c)
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
     c.tables = c.pfTables = c.hcSlots = c.scratch = nullptr; c.counter = nullptr; c.hcMaxBlock = 0;
-    c.ev0 = c.ev1 = nullptr; c.timed = 0; c.laneOrderOk = 1; c.ready = 0;
+    c.ev0 = c.ev1 = c.lastEv0 = c.lastEv1 = nullptr; c.timed = 0; c.laneOrderOk = 1; c.ready = 0;
 }
 
 int clamp_level(int level)                                       // reference lizard_compress.c:303-308
@@ -227,6 +240,40 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
     else if (hcLevel)              W = LZ_WAVES_HC;
     else if (lv == 21 || lv == 41) W = pfSmall ? (huf ? LZ_PF18_W_HUF : LZ_PF18_W) : LZ_PF_W;
     else                           W = LZ_PF22_W;
+    if (!perGroup) perGroup = W;
+    // Which arena?  (lizard_gpu_ctx.h, LzArena.)  The context's own unless this is a small launch on another stream than the one
+    // that used it last and that launch is still running; then: an extra arena last used by this stream, or an idle one, or a new
+    // one, or — all busy, none left to make — the extra ones in turn.
+    LzArena* ar = nullptr;                                                   // nullptr: the context's own
+    const bool smallLaunch = nBlocks < (size_t)c.cus * perGroup;
+    if (smallLaunch && !hcLevel && c.maxArenas > 1 && c.timed && c.lastStream != stream && hipEventQuery(c.ev1) == hipErrorNotReady) {
+        for (int i = 0; i < c.nExtra && !ar; i++) if (c.extra[i].lastStream == stream) ar = &c.extra[i];
+        for (int i = 0; i < c.nExtra && !ar; i++) if (!c.extra[i].timed || hipEventQuery(c.extra[i].ev1) == hipSuccess) ar = &c.extra[i];
+        if (!ar && c.nExtra < c.maxArenas - 1) {
+            LzArena& x = c.extra[c.nExtra];
+            memset(&x, 0, sizeof x);
+            hipError_t e = hipMalloc((void**)&x.scratch, (size_t)c.cus * LZ_MAX_WAVES * LZ_SCRATCH_BYTES);
+            if (e == hipSuccess) e = hipMalloc((void**)&x.counter, 64);
+            if (e == hipSuccess) e = hipEventCreate(&x.ev0);
+            if (e == hipSuccess) e = hipEventCreate(&x.ev1);
+            if (e == hipSuccess) {
+                ar = &x; c.nExtra++;
+                if (getenv("LIZARDGPU_VERBOSE")) fprintf(stderr, "liblizard_amd: device %d: arena %d for small launches on concurrent streams (LIZARDGPU_ARENAS caps them)\n", c.device, c.nExtra + 1);
+            } else {                                                         // no room: share the context's own after all
+                (void)hipGetLastError();
+                if (x.scratch) (void)hipFree(x.scratch);
+                if (x.counter) (void)hipFree(x.counter);
+                if (x.ev0) (void)hipEventDestroy(x.ev0);
+                if (x.ev1) (void)hipEventDestroy(x.ev1);
+                memset(&x, 0, sizeof x);
+            }
+        }
+        if (!ar && c.nExtra) { ar = &c.extra[c.nextExtra % c.nExtra]; c.nextExtra++; }
+        (void)hipGetLastError();                                             // (hipEventQuery's "not ready" is not an error to report)
+    }
+    uint8_t** const tablesAt = ar ? &ar->tables : &c.tables;
+    uint8_t** const pfTablesAt = ar ? &ar->pfTables : &c.pfTables;
+    if (ar) { a.scratch = ar->scratch; a.counter = ar->counter; }
     if (hcLevel) {
         // per wave: bins, links, and 6 bytes + 1 bit per block position (chain, packed chain words, hit bits).  One slot per resident
         // wave while that fits in about half of the free memory (19 GiB for 256 KiB blocks, 110 GiB for 4 MiB blocks); larger
@@ -255,13 +302,12 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
         }
         a.tables = c.hcSlots; a.tableStride = LZ_HC_SLOT_BYTES(c.hcMaxBlock); a.tableSlots = (u32)c.hcNSlots;
     } else if (lv == 11 || lv == 31 || lv == 22 || lv == 42) {
-        if (!c.tables) LZ_HIP(hipMalloc((void**)&c.tables, (size_t)c.cus * LZ_MAX_WAVES * LZ_TABWIDE_BYTES(18)));
-        a.tables = c.tables; a.tableStride = LZ_TABWIDE_BYTES(18);
-    } else {
-        if (!c.pfTables) LZ_HIP(hipMalloc((void**)&c.pfTables, (size_t)c.cus * LZ_MAX_WAVES * LZ_PF_SLOT_BYTES));
-        a.tables = c.pfTables; a.tableStride = LZ_PF_SLOT_BYTES;
+        if (!*tablesAt) LZ_HIP(hipMalloc((void**)tablesAt, (size_t)c.cus * LZ_MAX_WAVES * LZ_TABWIDE_BYTES(18)));
+        a.tables = *tablesAt; a.tableStride = LZ_TABWIDE_BYTES(18);
+    } else if (!((lv == 10 || lv == 30) && LZ_FAST12_SPLIT)) {             // (the producer / consumer form keeps every table in LDS)
+        if (!*pfTablesAt) LZ_HIP(hipMalloc((void**)pfTablesAt, (size_t)c.cus * LZ_MAX_WAVES * LZ_PF_SLOT_BYTES));
+        a.tables = *pfTablesAt; a.tableStride = LZ_PF_SLOT_BYTES;
     }
-    if (!perGroup) perGroup = W;
     u32 grid = (u32)((nBlocks + perGroup - 1) / perGroup);
     if (grid > (u32)c.cus) grid = (u32)c.cus;
 #if LZ_SPREAD_SMALL
@@ -274,9 +320,10 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
 #endif
     // The scratch arena, the tables and the block counter are shared by all launches on this device: a launch
     // on another stream first waits (on the GPU) for the previous one to finish.
-    if (c.timed) LZ_HIP(hipStreamWaitEvent(stream, c.ev1, 0));
-    LZ_HIP(hipMemsetAsync(c.counter, 0, 4, stream));
-    LZ_HIP(hipEventRecord(c.ev0, stream));
+    hipEvent_t const e0 = ar ? ar->ev0 : c.ev0, e1 = ar ? ar->ev1 : c.ev1;
+    if (ar ? (ar->timed && ar->lastStream != stream) : (c.timed != 0)) LZ_HIP(hipStreamWaitEvent(stream, e1, 0));
+    LZ_HIP(hipMemsetAsync(a.counter, 0, 4, stream));
+    LZ_HIP(hipEventRecord(e0, stream));
     if (k0) LZ_HIP(hipEventRecord(k0, stream));
     const dim3 g(grid), t(64 * W);
     switch (lv) {
@@ -307,9 +354,10 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
              break;
     }
     LZ_HIP(hipGetLastError());
-    LZ_HIP(hipEventRecord(c.ev1, stream));
+    LZ_HIP(hipEventRecord(e1, stream));
     if (k1) LZ_HIP(hipEventRecord(k1, stream));
-    c.timed = true;
+    if (ar) { ar->timed = 1; ar->lastStream = stream; } else { c.timed = true; c.lastStream = stream; }
+    c.lastEv0 = e0; c.lastEv1 = e1;
     c.lastSplit = LZ_FAST12_SPLIT && (lv == 10 || lv == 30);
     return 0;
 }
@@ -335,7 +383,7 @@ int launch_decompress(Ctx& c, const void* d_src, const u64* d_offsets, size_t sr
     hipLaunchKernelGGL(lz_decompress_kernel, dim3(grid), dim3(64 * LZ_WAVES_DEC), 0, stream, a);
     LZ_HIP(hipGetLastError());
     LZ_HIP(hipEventRecord(c.ev1, stream));
-    c.timed = true;
+    c.timed = true; c.lastStream = stream; c.lastEv0 = c.ev0; c.lastEv1 = c.ev1;
     c.hostKernelMs = -1.0f;
     return 0;
 }
@@ -481,6 +529,13 @@ int LizardGPU_profileDump(unsigned long long out[16])
 }
 #endif
 
+int LizardGPU_arenasInUse(void)
+{
+    Guard g;
+    if (g.rc) return 0;
+    return g.c->ready ? 1 + g.c->nExtra : 0;
+}
+
 float LizardGPU_lastKernelMs(void)
 {
     Guard g;
@@ -488,8 +543,8 @@ float LizardGPU_lastKernelMs(void)
     Ctx& c = *g.c;
     if (c.hostKernelMs >= 0.0f) return c.hostKernelMs;
     float ms = -1.0f;
-    if (c.timed && hipEventSynchronize(c.ev1) == hipSuccess) {
-        if (hipEventElapsedTime(&ms, c.ev0, c.ev1) != hipSuccess) ms = -1.0f;
+    if (c.lastEv1 && c.timed && hipEventSynchronize(c.lastEv1) == hipSuccess) {
+        if (hipEventElapsedTime(&ms, c.lastEv0, c.lastEv1) != hipSuccess) ms = -1.0f;
     }
     return ms;
 }

@@ -44,6 +44,20 @@ typedef struct LzCombine {
     double tBusySince;
 } LzCombine;
 
+/* A scratch arena with its block counter and the per-wave tables of the levels that keep them in global memory.  Every launch
+ * needs one to itself.  The context's own (LzCtx::scratch, counter, tables, pfTables, ev0/ev1) serves every launch that fills
+ * the machine, the hashChain levels and decompression, one after the other; a compress launch SMALLER than the machine that
+ * arrives on another stream while that one is busy gets one of up to LZ_ARENAS_MAX - 1 more (allocated on first need, 2.6 GiB +
+ * tables each; LIZARDGPU_ARENAS=1..4 caps the total, default 4), so that small launches of different streams run side by side
+ * on the CUs they leave each other. */
+#define LZ_ARENAS_MAX 4
+typedef struct LzArena {
+    uint8_t* scratch; uint32_t* counter; uint8_t* tables; uint8_t* pfTables;
+    hipEvent_t ev0, ev1;        /* around its last launch */
+    hipStream_t lastStream;
+    int timed;                  /* ev1 was recorded */
+} LzArena;
+
 typedef struct LzCtx {
     int   ready;
     int   device;
@@ -56,6 +70,10 @@ typedef struct LzCtx {
     uint32_t* counter;
     hipEvent_t ev0, ev1;
     int   timed;
+    hipStream_t lastStream;     /* of the last launch on the context's own arena */
+    LzArena extra[LZ_ARENAS_MAX - 1];
+    int   nExtra, maxArenas, nextExtra;
+    hipEvent_t lastEv0, lastEv1;   /* around the most recent launch, whichever arena it used (LizardGPU_lastKernelMs) */
     int   lastSplit;            /* the last compress launch was the producer / consumer form (profile builds: where the records are) */
     int   laneOrderOk;          /* self-check at context creation: lanes of one DS atomic are served in lane order */
     float hostKernelMs;         /* sum over the chunks of the last host-buffer call (< 0: last call was a device call) */

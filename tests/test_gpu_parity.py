@@ -235,6 +235,48 @@ def test_launches_on_two_streams_are_ordered(L):
             assert dst[i * stride:i * stride + int(sz[i])].cpu().numpy().tobytes() == want, (level, i)
 
 
+def test_small_launches_on_several_streams_run_side_by_side(L):
+    """A compress launch smaller than the machine that arrives on another stream while the context's arena is busy gets an arena
+    of its own (include/lizard_amd.h, LizardGPU_arenasInUse) and runs beside the first: four streams, launches of 16-96 blocks at
+    levels with LDS tables, global tables and both, queued without any host synchronisation — every block of every launch must be
+    bit-exact, more than one arena must have been made, and a launch that fills the machine afterwards is still right."""
+    import torch
+    from lizard_amd import api
+    L.LizardGPU_arenasInUse.restype = ctypes.c_int
+    bs = 262144
+    rnd = np.random.RandomState(3)
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    srcs = []
+    for k in range(4):
+        nb = int(rnd.choice([16, 48, 96]))
+        host = np.frombuffer(util.datagen(bs * nb, 0.3 + 0.15 * k, 0.0, 200 + k), dtype=np.uint8).copy()
+        srcs.append((host, torch.from_numpy(host).cuda(), nb))
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(6):
+        for k, st in enumerate(streams):
+            host, dev, nb = srcs[(k + rep) % 4]
+            level = (10, 21, 30, 11, 41, 22)[(k + 2 * rep) % 6]
+            with torch.cuda.stream(st):
+                outs.append((host, nb, level) + api.compress_blocks_device(dev, bs, level))
+    torch.cuda.synchronize()
+    arenas = L.LizardGPU_arenasInUse()
+    for host, nb, level, dst, sizes, stride in outs:
+        sz = sizes.cpu().numpy()
+        out = dst.cpu().numpy()
+        for i in range(nb):
+            want = util.oracle_compress(host[i * bs:(i + 1) * bs].tobytes(), level)
+            assert out[i * stride:i * stride + int(sz[i])].tobytes() == want, (level, i)
+    assert 2 <= arenas <= 4, arenas
+    big = torch.from_numpy(np.frombuffer(util.datagen(bs * 4096, 0.5, 0.0, 9), dtype=np.uint8).copy()).cuda()
+    with torch.cuda.stream(streams[1]):
+        dst, sizes, stride = api.compress_blocks_device(big, bs, 10)
+    torch.cuda.synchronize()
+    host = big.cpu().numpy(); sz = sizes.cpu().numpy()
+    for i in (0, 1, 2047, 4095):
+        assert dst[i * stride:i * stride + int(sz[i])].cpu().numpy().tobytes() == util.oracle_compress(host[i * bs:(i + 1) * bs].tobytes(), 10)
+
+
 def test_roundtrip_with_reference_decoder(L):
     """Full-size property: what the GPU writes decodes with the unmodified reference decoder."""
     ref = util.reference()
