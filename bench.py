@@ -39,7 +39,8 @@ installs a transport of the library's size exchange (LizardGPU_setCollectives) t
 code path, the same library entry points, no RCCL — `config.size_gather` names the transport; such a line is a functional
 check of the N > 1 path, not a scaling measurement (the ranks share a device).
 "one_block_callers": aggregate MB/s of 1..64 host threads calling the reference's one-block Lizard_compress at once (the
-combiner, tests/gpu_threads.c).  "frames": the reference's own frame entry point LizardF_compressFrame on a 4 GiB host buffer.
+combiner, tests/gpu_threads.c).  "concurrent_streams": 4 streams x 20 launches of 64 blocks queued without host synchronisation
+(a launch smaller than the machine gets an arena of its own and runs beside the others).  "frames": the reference's own frame entry point LizardF_compressFrame on a 4 GiB host buffer.
 "end_to_end" is the PCIe-inclusive rate of the host-buffer entry (LizardGPU_compressBlocks_host_packed) on a 4 GiB sample
 of the headline workload, from pageable and from pinned memory — never `value`.
 Only the cpu_baseline / verification legs touch oracle/ (as the checker); the timed region calls the product library.
@@ -618,6 +619,29 @@ def main():
                         "unit": "MB/s aggregate", "curve": json.loads(w.stdout.strip().splitlines()[-1])}
                 else:
                     out["one_block_callers"] = {"error": (w.stdout + w.stderr)[-300:]}
+            # small launches on several streams at once (arenas, include/lizard_amd.h LizardGPU_arenasInUse): 4 streams x 20 launches of
+            # 64 blocks each, queued without host synchronisation; wall time from the first launch to the last one's end
+            try:
+                S, R, nbs, bss = 4, 20, 64, 262144
+                sstreams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+                ssrc = src_all[:nbs * bss]
+                sbufs = [api.compress_blocks_device(ssrc, bss, 10) for _ in range(S)]
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(R):
+                    for k in range(S):
+                        with torch.cuda.stream(sstreams[k]):
+                            api.compress_blocks_device(ssrc, bss, 10, dst=sbufs[k][0], sizes=sbufs[k][1])
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                same = all(torch.equal(sbufs[0][1], sbufs[k][1]) for k in range(1, S))
+                L.LizardGPU_arenasInUse.restype = ctypes.c_int
+                out["concurrent_streams"] = {"sample": f"{S} streams x {R} launches of {nbs} x {bss} B blocks at level -10, device-resident, no host "
+                                                       "synchronisation in between; a launch smaller than the machine gets an arena of its own",
+                                             "arenas_in_use": int(L.LizardGPU_arenasInUse()), "MB_s": round(S * R * nbs * bss / dt / 1e6, 1),
+                                             "all_streams_same_sizes": bool(same)}
+            except Exception as ex:                               # noqa: BLE001 — a side measurement must not take the line down
+                out["concurrent_streams"] = {"error": repr(ex)[:200]}
             # PCIe-inclusive rate of the host-buffer entry on a 4 GiB sample of the headline workload (never `value`)
             nbe = min(16384, head["blocks_per_gpu"]); bs = 262144
             tools_datagen.datagen_device(src_all.data_ptr(), nbe, bs, 0.5, 0.0, 0, ctypes.c_void_p(stream.cuda_stream))

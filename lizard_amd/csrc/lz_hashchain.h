@@ -503,6 +503,21 @@ LZ_DEV u32 lz_hc_search(const u8* src, u32 nBlock, const LzHc& hc, u32 X, u32 iL
     return longest;
 }
 
+// The hit bit of position X (uniform): out of the 4 096 positions of bits the outer loop holds in registers when X lies there,
+// else one word from memory.  A search at a position whose bit is clear — the first one or a "wider" one (hashchain.h:45-107,
+// :109-186: both test the 4 bytes AT the position, :73 / :146) — finds nothing: no walk, no candidate bytes, no memory trip.
+#ifndef LZ_HC_SKIP_NOHIT
+#define LZ_HC_SKIP_NOHIT 1
+#endif
+LZ_DEV bool lz_hc_hit_at(const LzHc& hc, u64 bm, u32 bmBase, u32 X)
+{
+    const u32 wi = X >> 6, li = wi - bmBase;
+    u64 w;
+    if (li < 64u) w = ((u64)lz_readlane((u32)(bm >> 32), li) << 32) | lz_readlane((u32)bm, li);
+    else          w = lz_uniform64(hc.hits[wi]);
+    return (w >> (X & 63u)) & 1ull;
+}
+
 // Sub-block [S,E) of the block at src (hashchain.h:188-369).  The chain must have been built for the block.
 LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const LzHc& hc, LzStreams& st)
 {
@@ -529,7 +544,7 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const Lz
         LZ_PROF(st, 1);
         start0 = ip; ref0 = ref; ml0 = ml;                                                        // :209
     search2:
-        if (ip + ml < mflimit)                                                                    // :212-214
+        if (ip + ml < mflimit && (!LZ_HC_SKIP_NOHIT || lz_hc_hit_at(hc, bm, bmBase, (u32)(ip + ml - 2))))   // :212-214
             ml2 = (int)lz_hc_search(src, nBlock, hc, (u32)(ip + ml - 2), (u32)(ip + 1), (u32)matchlimit, (u32)ml, true, ref2, start2, st);
         else ml2 = ml;
         LZ_PROF(st, 2);
@@ -558,7 +573,7 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const Lz
             const int correction = new_ml - ((int)start2 - ip);
             if (correction > 0) { start2 += (u32)correction; ref2 += (u32)correction; ml2 -= correction; }
         }
-        if ((int)start2 + ml2 < mflimit)                                                          // :263-265
+        if ((int)start2 + ml2 < mflimit && (!LZ_HC_SKIP_NOHIT || lz_hc_hit_at(hc, bm, bmBase, start2 + (u32)ml2 - 3u)))   // :263-265
             ml3 = (int)lz_hc_search(src, nBlock, hc, start2 + (u32)ml2 - 3u, start2, (u32)matchlimit, (u32)ml2, true, ref3, start3, st);
         else ml3 = ml2;
         LZ_PROF(st, 3);
