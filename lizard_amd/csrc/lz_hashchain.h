@@ -57,12 +57,15 @@
 //   hits   u64[maxBlock/64 + 64]  one bit per position: "a search here finds a match" (lz_hc_hits)
 //   prev   u16[maxBlock]   distance to the previous head of the position's bucket (0 = none): the chain
 //   chain2 u32[maxBlock]   prev | two links at once << 16 (0 = the second is missing or out of every window): what the searches walk
+//   best   u32[maxBlock]   result of the FIRST search at the position (lz_hc_hits): length | offset << 16, 0 = nothing,
+//                          LZ_HC_BEST_OPEN = not decided ahead of the parse (the parse searches)
 #define LZ_HC_BINS_BYTES  (4u << LZ_HC_SEGLOG)
 #define LZ_HC_LINKS_BYTES (4u << LZ_HC_SEGLOG)
 #define LZ_HC_WINS_BYTES  8192u
 #define LZ_HC_HEADS_BYTES(maxBlock) ((size_t)(maxBlock) > (1u << LZ_HC_SEGLOG) ? (size_t)(4u << LZ_HC_HASHLOG) : 0u)
 #define LZ_HC_HITS_BYTES(maxBlock) ((((size_t)(maxBlock) + 63u) / 64u + 64u) * 8u)
-#define LZ_HC_SLOT_BYTES(maxBlock) ((size_t)LZ_HC_BINS_BYTES + LZ_HC_LINKS_BYTES + LZ_HC_WINS_BYTES + LZ_HC_HEADS_BYTES(maxBlock) + LZ_HC_HITS_BYTES(maxBlock) + 6u * (size_t)(maxBlock) + 256u)
+#define LZ_HC_SLOT_BYTES(maxBlock) ((size_t)LZ_HC_BINS_BYTES + LZ_HC_LINKS_BYTES + LZ_HC_WINS_BYTES + LZ_HC_HEADS_BYTES(maxBlock) + LZ_HC_HITS_BYTES(maxBlock) + 10u * (size_t)(maxBlock) + 512u)
+#define LZ_HC_BEST_OPEN 0xFFFFFFFFu
 
 struct LzHc {
     u32* bins;          // global
@@ -72,7 +75,9 @@ struct LzHc {
     u64* hits;          // global: bit p = a search at p finds a match
     u16* prev;          // global: per block position, distance to the previous head of its bucket (0 = none)
     u32* chain2;        // global: prev[p] | (prev[p] + prev[p - prev[p]]) << 16 (upper half 0 = no second link inside any window)
+    u32* best;          // global: the first search's result per position (see above)
     u32  searchNum;     // uniform
+    bool pre;           // uniform: best[] was filled for this block
 };
 
 template <int SEARCHLEN>
@@ -92,8 +97,10 @@ LZ_DEV void lz_hc_begin(LzHc& hc, void* slotMem, u32 maxBlock, u32 searchNum)
     hc.heads = (u32*)m;  m += LZ_HC_HEADS_BYTES(maxBlock);
     hc.hits = (u64*)m;   m += LZ_HC_HITS_BYTES(maxBlock);
     hc.prev = (u16*)m;   m += 2u * (size_t)maxBlock + 128u;
-    hc.chain2 = (u32*)m;
+    hc.chain2 = (u32*)m; m += 4u * (size_t)maxBlock + 128u;
+    hc.best = (u32*)m;
     hc.searchNum = searchNum;
+    hc.pre = false;
 }
 
 // Eight source bytes at each of the positions base + 64 k + lane, k = 0..7 (clamped inside the segment; unconditional).
@@ -354,18 +361,19 @@ LZ_DEV void lz_hc_build(const u8* src, u32 n, const LzHc& hc, const LzHufPool& p
 // is evaluated for all positions of the block ahead of the parse, LZ_HC_BULK x 64 positions at a time with their memory trips
 // side by side, into one bit per position; the outer loop becomes a bit scan.  (The parse used to walk the chains of 64
 // positions per round on its own serial path: three dependent memory trips per sequence.)
-#ifndef LZ_HC_BULK
-#define LZ_HC_BULK 8u
+#ifndef LZ_HC_BULK_PLAIN
+#define LZ_HC_BULK_PLAIN 8u
 #endif
-LZ_DEV void lz_hc_hits(const u8* src, u32 n, const LzHc& hc)
+// hit bits and packed chain words only (levels 13-15 / 34-36: the pass below does not pay there)
+LZ_DEV void lz_hc_hits_plain(const u8* src, u32 n, const LzHc& hc)
 {
     const u32 lane = lz_lane();
     const u32 nIns = n >= 8u ? n - 7u : 0u;                      // positions that have a chain link (lz_hc_build)
-    for (u32 base = 0; base < nIns; base += 64u * LZ_HC_BULK) {
-        u32 p[LZ_HC_BULK], m[LZ_HC_BULK], d[LZ_HC_BULK], f4[LZ_HC_BULK], two[LZ_HC_BULK];
-        bool walking[LZ_HC_BULK], hit[LZ_HC_BULK];
+    for (u32 base = 0; base < nIns; base += 64u * LZ_HC_BULK_PLAIN) {
+        u32 p[LZ_HC_BULK_PLAIN], m[LZ_HC_BULK_PLAIN], d[LZ_HC_BULK_PLAIN], f4[LZ_HC_BULK_PLAIN], two[LZ_HC_BULK_PLAIN];
+        bool walking[LZ_HC_BULK_PLAIN], hit[LZ_HC_BULK_PLAIN];
         #pragma unroll
-        for (u32 k = 0; k < LZ_HC_BULK; k++) {
+        for (u32 k = 0; k < LZ_HC_BULK_PLAIN; k++) {
             p[k] = base + k * 64u + lane;
             walking[k] = p[k] < nIns; hit[k] = false;
             m[k] = walking[k] ? p[k] : 0u;
@@ -375,31 +383,138 @@ LZ_DEV void lz_hc_hits(const u8* src, u32 n, const LzHc& hc)
         for (u32 a = 0; a < hc.searchNum; a++) {
             bool any = false;
             #pragma unroll
-            for (u32 k = 0; k < LZ_HC_BULK; k++) {
+            for (u32 k = 0; k < LZ_HC_BULK_PLAIN; k++) {
                 walking[k] = walking[k] && d[k] != 0u && p[k] - (m[k] - d[k]) <= LZ_MAX_DIST_LZ4;
                 any = any || walking[k];
                 m[k] = walking[k] ? m[k] - d[k] : m[k];
             }
             if (!lz_ballot(any)) break;
-            u32 c4[LZ_HC_BULK];
+            u32 c4[LZ_HC_BULK_PLAIN];
             #pragma unroll
-            for (u32 k = 0; k < LZ_HC_BULK; k++) { c4[k] = lz_ld32(src + m[k]); d[k] = hc.prev[m[k]]; }
+            for (u32 k = 0; k < LZ_HC_BULK_PLAIN; k++) { c4[k] = lz_ld32(src + m[k]); d[k] = hc.prev[m[k]]; }
             if (a == 0u) {                                       // the second link, for lz_hc_search's two-at-a-time walk
                 #pragma unroll
-                for (u32 k = 0; k < LZ_HC_BULK; k++) {
+                for (u32 k = 0; k < LZ_HC_BULK_PLAIN; k++) {
                     const u32 sum = (p[k] - m[k]) + d[k];
                     if (walking[k] && d[k] != 0u && sum <= LZ_MAX_DIST_LZ4) two[k] |= sum << 16;
                 }
             }
             #pragma unroll
-            for (u32 k = 0; k < LZ_HC_BULK; k++)
+            for (u32 k = 0; k < LZ_HC_BULK_PLAIN; k++)
                 if (walking[k] && p[k] - m[k] >= LZ_MIN_OFFSET && c4[k] == f4[k]) { hit[k] = true; walking[k] = false; }
         }
         u64 mine = 0;
         #pragma unroll
-        for (u32 k = 0; k < LZ_HC_BULK; k++) {
+        for (u32 k = 0; k < LZ_HC_BULK_PLAIN; k++) {
             const u64 w = lz_ballot(hit[k]); mine = lane == k ? w : mine;
             if (p[k] < nIns) hc.chain2[p[k]] = two[k];
+        }
+        if (lane < LZ_HC_BULK_PLAIN && base + lane * 64u < nIns) hc.hits[(base >> 6) + lane] = mine;
+    }
+    lz_wave_sync();
+}
+
+//
+// Round 4: the FIRST search of a sequence (Lizard_InsertAndFindBestMatch, hashchain.h:45-107: longest forward match among the first
+// searchNum chain candidates, the earlier one on ties) is a function of the position alone as well — only the two "wider" searches of
+// the arbitration (:236-300) depend on the running match.  After the wider searches at positions without a hit were dropped (below),
+// first searches are 70-85 % of the searches the parse still runs, each three or four dependent memory trips on the wave's serial
+// path.  This pass therefore goes on past the first hit: every candidate brings its chain link AND 16 bytes in one trip, the
+// position's own 16 bytes are in registers, so the 4-byte test (:73) and the forward length (:76) of a candidate come out of that trip,
+// LZ_HC_BULK x 64 positions side by side.  best[p] = length | offset << 16.  Left to the parse (LZ_HC_BEST_OPEN): a candidate that
+// agrees in all 16 bytes with more room behind them (5-18 % of the first searches on the bench data), and positions with more than
+// LZ_HC_PRE_STEPS candidates (their hit bit is still exact: the walk goes on with the 4-byte test alone until the first hit).
+#ifndef LZ_HC_BULK
+#define LZ_HC_BULK 4u
+#endif
+#ifndef LZ_HC_PRE_STEPS
+#define LZ_HC_PRE_STEPS 4u
+#endif
+#ifndef LZ_HC_PREPASS
+#define LZ_HC_PREPASS 1
+#endif
+
+LZ_DEV void lz_hc_hits(const u8* src, u32 n, const LzHc& hc)
+{
+    const u32 lane = lz_lane();
+    const u32 nIns = n >= 8u ? n - 7u : 0u;                      // positions that have a chain link (lz_hc_build)
+    for (u32 base = 0; base < nIns; base += 64u * LZ_HC_BULK) {
+        u32 m[LZ_HC_BULK], d[LZ_HC_BULK], two[LZ_HC_BULK], best[LZ_HC_BULK];
+        u64 pA[LZ_HC_BULK], pB[LZ_HC_BULK];
+        u32 state[LZ_HC_BULK];                                   // bit 0 walking, bit 1 hit, bit 2 open
+        #pragma unroll
+        for (u32 k = 0; k < LZ_HC_BULK; k++) {
+            const u32 p = base + k * 64u + lane;
+            state[k] = p < nIns ? 1u : 0u; best[k] = 0u;
+            m[k] = p < nIns ? p : 0u;
+            d[k] = hc.prev[m[k]];
+            two[k] = d[k];                                       // becomes prev | two links << 16
+            // (16 bytes at a position below nIns = n - 7 may reach past the block by up to 8: the second load is clamped)
+            pA[k] = lz_ld64(src + m[k]);
+            pB[k] = lz_ld64(src + (m[k] + 16u <= n ? m[k] + 8u : m[k]));
+        }
+        for (u32 a = 0; a < hc.searchNum; a++) {
+            bool any = false;
+            #pragma unroll
+            for (u32 k = 0; k < LZ_HC_BULK; k++) {
+                const u32 p = base + k * 64u + lane;
+                const bool w = (state[k] & 1u) && d[k] != 0u && p - (m[k] - d[k]) <= LZ_MAX_DIST_LZ4;
+                state[k] = (state[k] & ~1u) | (w ? 1u : 0u);
+                any = any || w;
+                m[k] = w ? m[k] - d[k] : m[k];
+            }
+            if (!lz_ballot(any)) break;
+            const bool full = LZ_HC_PREPASS && a < LZ_HC_PRE_STEPS;          // uniform: measure the candidates of this step
+            u64 cA[LZ_HC_BULK], cB[LZ_HC_BULK];
+            #pragma unroll
+            for (u32 k = 0; k < LZ_HC_BULK; k++) {                   // (a candidate lies below its position: its 16 bytes are inside the block when the position's are)
+                const u32 p = base + k * 64u + lane;
+                if (full) { cA[k] = lz_ld64(src + m[k]); cB[k] = lz_ld64(src + (p + 16u <= n ? m[k] + 8u : m[k])); }
+                else      { cA[k] = lz_ld32(src + m[k]); cB[k] = 0; }
+                d[k] = hc.prev[m[k]];
+            }
+            if (a == 0u) {                                       // the second link, for lz_hc_search's two-at-a-time walk
+                #pragma unroll
+                for (u32 k = 0; k < LZ_HC_BULK; k++) {
+                    const u32 p = base + k * 64u + lane;
+                    const u32 sum = (p - m[k]) + d[k];
+                    if ((state[k] & 1u) && d[k] != 0u && sum <= LZ_MAX_DIST_LZ4) two[k] |= sum << 16;
+                }
+            }
+            #pragma unroll
+            for (u32 k = 0; k < LZ_HC_BULK; k++) {
+                const u32 p = base + k * 64u + lane;
+                const bool walking = state[k] & 1u;
+                const bool ok = walking && p - m[k] >= LZ_MIN_OFFSET && (u32)cA[k] == (u32)pA[k];             // :73
+                if (full) {
+                    if (ok) {
+                        // the sub-block the position belongs to bounds its matches (matchlimit = E - LASTLITERALS, lz_parse_hashchain);
+                        // a position the parse never searches from (>= mflimit) gets room 0
+                        const u32 S0 = p & ~(LZ_SUBBLOCK - 1u);
+                        const u32 E = S0 + LZ_SUBBLOCK < n ? S0 + LZ_SUBBLOCK : n;
+                        const u32 maxFwd = (E >= LZ_MFLIMIT && p < E - LZ_MFLIMIT) ? E - LZ_LASTLITERALS - p : 0u;
+                        const u64 x = pA[k] ^ cA[k], y = pB[k] ^ cB[k];
+                        const u32 seen = p + 16u <= n ? 16u : 8u;    // bytes the loads may compare (the second was clamped near the end of the block)
+                        const u32 common = x ? lz_ctz64(x) >> 3 : (seen > 8u && y) ? 8u + (lz_ctz64(y) >> 3) : seen;
+                        const u32 mlt = common < maxFwd ? common : maxFwd;
+                        state[k] |= 2u;
+                        if (common >= seen && maxFwd > seen) state[k] = (state[k] | 4u) & ~1u;       // longer than what was fetched: the parse decides
+                        else if (mlt > (best[k] & 0xFFFFu)) best[k] = mlt | ((p - m[k]) << 16);     // strictly longer: the earlier candidate wins ties
+                    }
+                } else if (ok) {
+                    state[k] = (state[k] | 2u | (LZ_HC_PREPASS ? 4u : 0u)) & ~1u;                      // found by the 4-byte test alone: not measured
+                } else if (LZ_HC_PREPASS && walking && (state[k] & 2u)) state[k] = (state[k] | 4u) & ~1u;   // a hit is known; what is left could beat it
+            }
+        }
+        u64 mine = 0;
+        #pragma unroll
+        for (u32 k = 0; k < LZ_HC_BULK; k++) {
+            const u32 p = base + k * 64u + lane;
+            const u64 w = lz_ballot((state[k] & 2u) != 0u); mine = lane == k ? w : mine;
+            if (p < nIns) {
+                hc.chain2[p] = two[k];
+                hc.best[p] = (!LZ_HC_PREPASS || (state[k] & 4u)) ? LZ_HC_BEST_OPEN : best[k];
+            }
         }
         if (lane < LZ_HC_BULK && base + lane * 64u < nIns) hc.hits[(base >> 6) + lane] = mine;
     }
@@ -528,6 +643,9 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const Lz
     u32 ref = 0, ref2 = 0, ref3 = 0, ref0 = 0, start2 = 0, start3 = 0, dummy = 0;
     u32 bmBase = 0xFFFF0000u;                                    // first word of the hit bits held in bm (none yet)
     u64 bm = 0;
+    // The first-search results of 128 positions (best[bwBase + lane], best[bwBase + 64 + lane]) ride in two registers: one coalesced
+    // trip per 128 positions instead of a dependent one per sequence.
+    u32 bwBase = 0xFFFF0000u, bwA = 0, bwB = 0;
     for (;;) {
         // ---------------- :204-206: first position with any match: a scan of the hit bits ----------------
         for (;;) {
@@ -540,12 +658,27 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const Lz
             ip = (int)((wi + 1u) << 6);
         }
         LZ_PROF(st, 0);
-        ml = (int)lz_hc_search(src, nBlock, hc, (u32)ip, (u32)ip, (u32)matchlimit, 0u, false, ref, dummy, st);
+        {
+            u32 bw = LZ_HC_BEST_OPEN;                            // the first search, decided ahead of the parse
+            if (LZ_HC_PREPASS && hc.pre) {
+                if ((u32)ip - bwBase >= 128u) {
+                    bwBase = (u32)ip & ~63u;
+                    const u32 last = nBlock - 1u, ia = bwBase + lane, ib = bwBase + 64u + lane;
+                    bwA = hc.best[ia < last ? ia : last]; bwB = hc.best[ib < last ? ib : last];
+                }
+                const u32 o = (u32)ip - bwBase;
+                bw = o < 64u ? lz_readlane(bwA, o) : lz_readlane(bwB, o - 64u);
+            }
+            if (bw != LZ_HC_BEST_OPEN) { LZ_STAT(19); ml = (int)(bw & 0xFFFFu); ref = (u32)ip - (bw >> 16); }
+            else { LZ_STAT(20); ml = (int)lz_hc_search(src, nBlock, hc, (u32)ip, (u32)ip, (u32)matchlimit, 0u, false, ref, dummy, st); }
+        }
         LZ_PROF(st, 1);
+        if (ml < 16) LZ_STAT(25); else if (ml < 24) LZ_STAT(26); else if (ml < 32) LZ_STAT(27); else LZ_STAT(28);
         start0 = ip; ref0 = ref; ml0 = ml;                                                        // :209
     search2:
+        if (ip + ml < mflimit) LZ_STAT(21);
         if (ip + ml < mflimit && (!LZ_HC_SKIP_NOHIT || lz_hc_hit_at(hc, bm, bmBase, (u32)(ip + ml - 2))))   // :212-214
-            ml2 = (int)lz_hc_search(src, nBlock, hc, (u32)(ip + ml - 2), (u32)(ip + 1), (u32)matchlimit, (u32)ml, true, ref2, start2, st);
+            { LZ_STAT(22); ml2 = (int)lz_hc_search(src, nBlock, hc, (u32)(ip + ml - 2), (u32)(ip + 1), (u32)matchlimit, (u32)ml, true, ref2, start2, st); }
         else ml2 = ml;
         LZ_PROF(st, 2);
         if (ml2 == ml) {                                                                          // :216-219
@@ -573,8 +706,9 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const Lz
             const int correction = new_ml - ((int)start2 - ip);
             if (correction > 0) { start2 += (u32)correction; ref2 += (u32)correction; ml2 -= correction; }
         }
+        if ((int)start2 + ml2 < mflimit) LZ_STAT(23);
         if ((int)start2 + ml2 < mflimit && (!LZ_HC_SKIP_NOHIT || lz_hc_hit_at(hc, bm, bmBase, start2 + (u32)ml2 - 3u)))   // :263-265
-            ml3 = (int)lz_hc_search(src, nBlock, hc, start2 + (u32)ml2 - 3u, start2, (u32)matchlimit, (u32)ml2, true, ref3, start3, st);
+            { LZ_STAT(24); ml3 = (int)lz_hc_search(src, nBlock, hc, start2 + (u32)ml2 - 3u, start2, (u32)matchlimit, (u32)ml2, true, ref3, start3, st); }
         else ml3 = ml2;
         LZ_PROF(st, 3);
         if (ml3 == ml2) {                                                                         // :267-275
