@@ -7,6 +7,7 @@
 #   bash scripts/gpu_session.sh validate <tag>
 #        the round's validation pass: gpu_quick, pytest -m gpu, smoke, bench.py, rocprofv3 --kernel-trace --stats of the same
 #        command, fabric-traffic counter passes of the bench configurations (scripts/gpu_traffic.sh), all-level gpu_bench lines
+#   bash scripts/gpu_session.sh validate_slim <tag>    the same without gpu_quick, the rocprofv3 pass of the whole bench and the 11/13 counter passes
 #   bash scripts/gpu_session.sh traffic <tag> "<level> <blockSize> <nBlocks>" ...     (scripts/gpu_traffic.sh)
 #   bash scripts/gpu_session.sh sq <tag> <variant|base> <level> <blockSize> <nBlocks>  (scripts/gpu_sq_counters.sh)
 MODE=$1; TAG=$2; shift; shift
@@ -36,5 +37,17 @@ validate)
   bash scripts/gpu_traffic.sh $TAG "10 262144 65536" "10 4194304 6656" "30 262144 16384" "21 262144 16384" "11 262144 16384" "13 262144 16384" > $O/traffic.log 2>&1
   grep -E "^L" $O/traffic.log | tee -a $O/summary.txt
   for l in 11 31 13 14 15 16 17 35 22 41 42; do timeout 300 tests/gpu_bench $l 262144 16384 2 50 1024 2>&1 | tail -1 | tee -a $O/summary.txt; done ;;
+validate_slim)
+  # the validation pass when GPU minutes are short: GPU tests, smoke, bench line, rocprofv3 of the headline configuration alone,
+  # counter passes of the four bench configurations, one gpu_bench line per remaining level
+  ( timeout 1500 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?" ) | tee $O/summary.txt; tail -4 $O/pytest.log | tee -a $O/summary.txt
+  ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" ) | tee -a $O/summary.txt
+  ( timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" ) | tee -a $O/summary.txt
+  ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/rocprof_headline -o headline -- python $R/bench.py --headline-only --no-cpu > $R/$O/bench_headline_under_rocprof.json 2> $R/$O/rocprof_headline.err; echo "rocprof headline rc=$?" ) | tee -a $O/summary.txt
+  find $O/rocprof_headline -name "*kernel_stats.csv" -exec cp {} $O/rocprofv3_kernel_stats_bench_headline_only.csv \;
+  find $O/rocprof_headline -name "*.csv" -size +1M -delete; find $O/rocprof_headline -name "*.db" -delete
+  bash scripts/gpu_traffic.sh $TAG "10 262144 65536" "10 4194304 6656" "30 262144 16384" "21 262144 16384" > $O/traffic.log 2>&1
+  grep -E "^L" $O/traffic.log | tee -a $O/summary.txt
+  for l in 11 31 13 14 15 16 17 35 37 22 41 42; do timeout 300 tests/gpu_bench $l 262144 16384 2 50 1024 2>&1 | tail -1 | tee -a $O/summary.txt; done ;;
 *) echo "unknown mode $MODE"; exit 2 ;;
 esac
