@@ -173,7 +173,7 @@ void ctx_release(Ctx& c)
     if (c.tables) (void)hipFree(c.tables);
     if (c.pfTables) (void)hipFree(c.pfTables);
     if (c.hcSlots) (void)hipFree(c.hcSlots);
-    c.hcNSlots = 0;
+    c.hcNSlots = 0; c.hcHasBest = 0; c.hcSlotBytes = 0;
     if (c.scratch) (void)hipFree(c.scratch);
     if (c.counter) (void)hipFree(c.counter);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
@@ -275,12 +275,18 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
     uint8_t** const pfTablesAt = ar ? &ar->pfTables : &c.pfTables;
     if (ar) { a.scratch = ar->scratch; a.counter = ar->counter; }
     if (hcLevel) {
-        // per wave: bins, links, and 6 bytes + 1 bit per block position (chain, packed chain words, hit bits).  One slot per resident
-        // wave while that fits in about half of the free memory (19 GiB for 256 KiB blocks, 110 GiB for 4 MiB blocks); larger
-        // blocks get as many slots as fit and the other waves leave (lz_wave_main).
+        // per wave: bins, links, and 6 bytes + 1 bit per block position (chain, packed chain words, hit bits) — 10 bytes at levels
+        // 16/17/37/38, whose first searches are decided ahead of the parse (best[], the LAST array of the slot: the other levels'
+        // slots simply end before it).  One slot per resident wave while that fits in about half of the free memory (256 KiB
+        // blocks: 14 GiB, 18 GiB with best[]; 4 MiB blocks: 110 GiB, or as many slots as fit under the 128 GiB cap with best[]);
+        // larger blocks get as many slots as fit and the other waves leave (lz_wave_main).
         const size_t cap = (blockSize + 65535u) & ~(size_t)65535u;
-        if (!c.hcSlots || c.hcMaxBlock < cap) {
-            if (c.hcSlots) { LZ_HIP(hipDeviceSynchronize()); LZ_HIP(hipFree(c.hcSlots)); c.hcSlots = nullptr; c.hcMaxBlock = 0; c.hcNSlots = 0; }
+        const bool needBest = lv == 16 || lv == 17 || lv == 37 || lv == 38;
+        if (!c.hcSlots || c.hcMaxBlock < cap || (needBest && !c.hcHasBest)) {
+            const bool withBest = needBest || c.hcHasBest;
+            const size_t capA = cap > c.hcMaxBlock ? cap : c.hcMaxBlock;                 // (a re-allocation never shrinks what the slots take)
+            const size_t slotBytes = LZ_HC_SLOT_BYTES(capA) - (withBest ? 0u : 4u * capA);
+            if (c.hcSlots) { LZ_HIP(hipDeviceSynchronize()); LZ_HIP(hipFree(c.hcSlots)); c.hcSlots = nullptr; c.hcNSlots = 0; }
             size_t freeB = 0, totalB = 0;
             LZ_HIP(hipMemGetInfo(&freeB, &totalB));
             size_t budget = freeB / 2u;
@@ -291,16 +297,16 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
                 const size_t mb = (size_t)strtoull(e, nullptr, 10);
                 if (mb > 0 && (mb << 20) < budget) budget = mb << 20;
             }
-            size_t nSlots = budget / LZ_HC_SLOT_BYTES(cap);
+            size_t nSlots = budget / slotBytes;
             if (nSlots > (size_t)c.cus * LZ_MAX_WAVES) nSlots = (size_t)c.cus * LZ_MAX_WAVES;
-            if (nSlots == 0) { snprintf(t_err, sizeof t_err, "level %d: no room for a hashChain work area of %zu bytes", lv, (size_t)LZ_HC_SLOT_BYTES(cap)); return -LIZARDGPU_ERR_NOMEM; }
-            LZ_HIP(hipMalloc((void**)&c.hcSlots, nSlots * LZ_HC_SLOT_BYTES(cap)));
-            c.hcMaxBlock = cap; c.hcNSlots = nSlots;
+            if (nSlots == 0) { snprintf(t_err, sizeof t_err, "level %d: no room for a hashChain work area of %zu bytes", lv, slotBytes); return -LIZARDGPU_ERR_NOMEM; }
+            LZ_HIP(hipMalloc((void**)&c.hcSlots, nSlots * slotBytes));
+            c.hcMaxBlock = capA; c.hcNSlots = nSlots; c.hcHasBest = withBest; c.hcSlotBytes = slotBytes;
             if (getenv("LIZARDGPU_VERBOSE"))
                 fprintf(stderr, "liblizard_amd: device %d: hashChain levels reserve %zu work areas of %zu bytes (%.1f GiB of %.1f GiB free; LIZARDGPU_HC_WORKAREA_MB caps it)\n",
-                        c.device, nSlots, (size_t)LZ_HC_SLOT_BYTES(cap), (double)(nSlots * LZ_HC_SLOT_BYTES(cap)) / (double)(1u << 30), (double)freeB / (double)(1u << 30));
+                        c.device, nSlots, slotBytes, (double)(nSlots * slotBytes) / (double)(1u << 30), (double)freeB / (double)(1u << 30));
         }
-        a.tables = c.hcSlots; a.tableStride = LZ_HC_SLOT_BYTES(c.hcMaxBlock); a.tableSlots = (u32)c.hcNSlots;
+        a.tables = c.hcSlots; a.tableStride = c.hcSlotBytes; a.tableSlots = (u32)c.hcNSlots;
     } else if (lv == 11 || lv == 31 || lv == 22 || lv == 42) {
         if (!*tablesAt) LZ_HIP(hipMalloc((void**)tablesAt, (size_t)c.cus * LZ_MAX_WAVES * LZ_TABWIDE_BYTES(18)));
         a.tables = *tablesAt; a.tableStride = LZ_TABWIDE_BYTES(18);

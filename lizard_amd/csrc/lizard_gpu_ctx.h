@@ -65,7 +65,8 @@ typedef struct LzCtx {
     uint8_t* tables;            /* levels 11/31/22/42, allocated on first use */
     uint8_t* pfTables;          /* levels 21/41: 64 KiB per resident wave for the waves whose table is not in LDS */
     uint8_t* hcSlots;           /* hashChain levels, allocated on first use / when a larger block size arrives */
-    size_t   hcMaxBlock, hcNSlots;
+    size_t   hcMaxBlock, hcNSlots, hcSlotBytes;
+    int      hcHasBest;         /* the slots end with the first-search table of levels 16/17/37/38 */
     uint8_t* scratch;
     uint32_t* counter;
     hipEvent_t ev0, ev1;
