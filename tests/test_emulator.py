@@ -245,6 +245,27 @@ def test_emulated_hashchain_block_above_4mib():
     assert emul_compress(data, 13, 1) == util.oracle_compress(data, 13)
 
 
+def test_emulated_hashchain_searches_decided_ahead_of_the_parse():
+    """Round 4, lz_hashchain.h: (1) a wider search (hashchain.h:212-214, :263-265) at a position whose hit bit is clear never
+    starts — at every hashChain level; (2) at levels 16/17/37/38 the first search of a position comes out of the table the hit pass
+    fills (4 candidates deep, 16 bytes each), the rest — longer matches, longer chains — stays with the parse; levels 13-15 keep
+    the plain hit pass.  Counted by the emulator's LZ_STAT marks, outputs equal to the oracle's."""
+    E = util.emulator()
+    out = (ctypes.c_ulonglong * 64)()
+    data = [util.datagen(200000, 0.5, 0.0, 5), util.datagen(140000, 0.25, 0.0, 6), (b"abcdefgh" * 3000 + bytes(range(256)) * 40) * 2]
+    for level in (13, 15, 16, 17, 37):
+        E.emul_stats(out, 1)
+        for i, d in enumerate(data):
+            assert emul_compress(d, level, 1 + i) == util.oracle_compress(d, level), (level, i)
+        E.emul_stats(out, 1)
+        from_table, searched, w2, w2_run, w3, w3_run = out[19], out[20], out[21], out[22], out[23], out[24]
+        assert w2_run < w2 and w3_run <= w3 and w2_run > 0, (level, w2, w2_run)          # some wider searches skipped, some run
+        if level in (16, 17, 37):
+            assert from_table > searched > 0, (level, from_table, searched)                # most first searches read, some still searched
+        else:
+            assert from_table == 0 and searched > 0, (level, from_table)
+
+
 def test_emulated_pricefast_chained_paths_are_reached():
     """Levels 21 / 41 / 22 take several sequences out of one round and run the lazy step (pricefast.h:184-228) from the lanes'
     registers (lz_pricefast.h, "several sequences out of one round").  The emulator counts the parser's LZ_STAT marks: every exit
