@@ -191,6 +191,25 @@ def test_reference_cli_one_byte_tail_block(tmp_path):
         assert dst.raw[:n] == frame, k
 
 
+def test_reference_frametest_without_a_device_exercises_the_frame_state_machines():
+    """The reference's tests/frametest.c linked against liblizard_amd.so alone also runs where there is no GPU: LizardF_compress*
+    then stores every block raw (the reference's own behaviour on a 0 from the block compressor, lib/lizard_frame.c:463-467), and
+    everything else the program checks is host code of this library — frame headers, every preference, random segmentation of
+    Update / flush / End, the bound contracts, LizardF_decompress under random input and output buffer sizes, skippable frames,
+    content checksums, error reporting.  30 000 of its randomised tests, two seeds."""
+    exe = os.path.join(util.ROOT, "oracle", "_ref", "frametest_amd")
+    if not os.path.exists(exe):
+        util.reference()                                                     # builds oracle/_ref when the checkout is present
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/frametest_amd not built")
+    from lizard_amd import _lib
+    _lib.build()
+    for seed in (4242, 7254):
+        r = subprocess.run([exe, "-s%d" % seed, "-i15000"], capture_output=True, text=True, timeout=600)
+        tail = (r.stdout + r.stderr).replace("\r", "\n")[-1500:]
+        assert r.returncode == 0 and "All tests completed" in tail, tail
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("prog,args", [("fuzzer_amd", ["-T10s"]), ("frametest_amd", ["-T10s"]), ("fullbench_amd", ["-i1"])])
 def test_reference_test_programs_on_the_gpu_library(prog, args, tmp_path):
