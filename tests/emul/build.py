@@ -17,13 +17,24 @@ def build(force=False):
     out = OUT if not defs else os.path.join(HERE, "libemul_variant.so")
     stamp = out + ".defs"
     same = not defs or (os.path.exists(stamp) and open(stamp).read() == " ".join(defs))
-    if not force and same and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in DEPS):
+    def fresh():
+        return same and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in DEPS)
+    if not force and fresh():
         return out
-    cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-fno-omit-frame-pointer", "-Wall", "-Wextra",
-           "-Wno-unused-function", "-Wno-unknown-pragmas", "-pthread", "-I", HERE, "-o", out] + defs + SRCS
-    subprocess.check_call(cmd)
-    if defs:
-        open(stamp, "w").write(" ".join(defs))
+    # several test processes may find the library stale at once (pytest-xdist, soaks started together): one of them builds, into a
+    # temporary file that is renamed into place (processes that already loaded the old file keep their mapping), the others wait
+    import fcntl
+    with open(out + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and fresh():
+            return out
+        tmp = "%s.tmp.%d" % (out, os.getpid())
+        cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-fno-omit-frame-pointer", "-Wall", "-Wextra",
+               "-Wno-unused-function", "-Wno-unknown-pragmas", "-pthread", "-I", HERE, "-o", tmp] + defs + SRCS
+        subprocess.check_call(cmd)
+        os.replace(tmp, out)
+        if defs:
+            open(stamp, "w").write(" ".join(defs))
     return out
 
 
