@@ -189,6 +189,42 @@ static size_t read_weights(const u8* src, size_t srcSize, u8* wt, u32* nbSym, u3
     return iSize + 1;
 }
 
+/* Backward bit reader of one huff0 bitstream (the construction of bitstream.h:270-347): `c` = the 8 bytes at ptr (little endian),
+ * of which the top `used` bits are consumed; the next bits are (c << used) >> (64 - nb).  Streams shorter than 8 bytes sit in the
+ * low bytes of c with ptr == start.  Used up exactly <=> ptr == start && used == 64. */
+typedef struct { const u8* start; const u8* ptr; u64 c; u32 used; } HufRd;
+static u64 hufrd_ld64(const u8* p) { u64 w; memcpy(&w, p, 8); return w; }      /* (little-endian hosts: x86-64) */
+static int hufrd_init(HufRd* r, const u8* p, size_t n)
+{
+    u32 last, hb;
+    size_t i;
+    if (n == 0) return 0;
+    last = p[n - 1];
+    if (!last) return 0;                                                       /* no end mark */
+    hb = 31u - (u32)__builtin_clz(last);
+    r->start = p;
+    if (n >= 8) { r->ptr = p + n - 8; r->c = hufrd_ld64(r->ptr); r->used = 8 - hb; }
+    else {
+        r->ptr = p; r->c = 0;
+        for (i = 0; i < n; i++) r->c |= (u64)p[i] << (8 * i);
+        r->used = (8 - hb) + (u32)(8 - n) * 8;
+    }
+    return 1;
+}
+static int hufrd_fast(const HufRd* r) { return r->ptr >= r->start + 8; }     /* a whole word can be refilled (then used <= 63 + ...: see callers) */
+static void hufrd_reload_fast(HufRd* r) { r->ptr -= r->used >> 3; r->used &= 7; r->c = hufrd_ld64(r->ptr); }
+static void hufrd_reload(HufRd* r)
+{
+    if (r->used > 64) r->used = 65;                                            /* read past the start: stays wrong, reported at the end */
+    if (hufrd_fast(r)) { hufrd_reload_fast(r); return; }
+    if (r->ptr == r->start) return;
+    {
+        u32 nb = r->used >> 3;
+        if ((size_t)(r->ptr - r->start) < nb) nb = (u32)(r->ptr - r->start);
+        r->ptr -= nb; r->used -= nb * 8; r->c = hufrd_ld64(r->ptr);
+    }
+}
+
 /* dst[0..n) from cSrc[0..cSize) (HUF_decompress, huf_decompress.c:832-845).  1 = ok, 0 = corrupt. */
 static int huf_decompress(u8* dst, size_t n, const u8* cSrc, size_t cSize)
 {
@@ -218,10 +254,15 @@ static int huf_decompress(u8* dst, size_t n, const u8* cSrc, size_t cSize)
             }
         }
     }
-    {   /* HUF_decompress4X2_usingDTable: 6-byte jump table, 4 segments of ceil(n/4) symbols (the last one takes the rest) */
+    {   /* HUF_decompress4X2_usingDTable: 6-byte jump table, 4 segments of ceil(n/4) symbols (the last one takes the rest).
+         * The four bitstreams are independent: they are decoded side by side, four symbols per stream between two refills (a symbol
+         * takes at most 12 bits), which is where the speed of the reference's decoder comes from as well (huf_decompress.c:222-262). */
         const u8* ip = cSrc + hSize;
         const size_t rem = cSize - hSize;
-        size_t len[4], off[4], cnt[4], seg;
+        size_t len[4], off[4], cnt[4], done[4], seg, quads, q;
+        HufRd r[4];
+        u8* o[4];
+        const u32 shift = 64 - tableLog;
         int k;
         if (rem < 10) return 0;
         len[0] = le16(ip); len[1] = le16(ip + 2); len[2] = le16(ip + 4);
@@ -232,40 +273,39 @@ static int huf_decompress(u8* dst, size_t n, const u8* cSrc, size_t cSize)
         if (3 * seg > n) return 0;
         cnt[0] = cnt[1] = cnt[2] = seg; cnt[3] = n - 3 * seg;
         for (k = 0; k < 4; k++) {
-            /* backward reader with a 64-bit window: `acc` holds the next `avail` unread bits left-aligned; refilled a byte at a time
-             * from the end of the segment towards its start; below the start the stream reads as zeros, and a stream that is not
-             * used up exactly is corrupt (BIT_endOfDStream, huf_decompress.c:197-199) */
-            const u8* sp = ip + 6 + off[k];
-            const size_t L = len[k];
-            u8* o = dst + (size_t)k * seg;
-            u64 acc = 0;
-            u32 avail = 0, hb, last;
-            size_t bytePos = L, i;
-            long remaining;
-            const u32 shift = 64 - tableLog;
-            if (L == 0) return 0;
-            last = sp[L - 1];
-            if (!last) return 0;
-            hb = 31u - (u32)__builtin_clz(last);
-            remaining = (long)(8 * (L - 1)) + (long)hb;
-#define REFILL() do { \
-                if (avail <= 32) { \
-                    if (bytePos >= 4) { u32 w4; memcpy(&w4, sp + bytePos - 4, 4); acc |= (u64)w4 << (32 - avail); avail += 32; bytePos -= 4; } \
-                    else while (bytePos > 0 && avail <= 56) { bytePos--; acc |= (u64)sp[bytePos] << (56 - avail); avail += 8; } \
-                } } while (0)
-            REFILL();
-            acc <<= (8 - hb); avail -= (8 - hb);                              /* the end mark and the padding above it */
-            for (i = 0; i < cnt[k]; i++) {
-                u32 e, nb;
-                REFILL();
-                e = dt[(u32)(acc >> shift)];
-                nb = e >> 8;
-                o[i] = (u8)e;
-                acc <<= nb; avail = avail > nb ? avail - nb : 0;
-                remaining -= (long)nb;
+            if (!hufrd_init(&r[k], ip + 6 + off[k], len[k])) return 0;
+            o[k] = dst + (size_t)k * seg; done[k] = 0;
+        }
+        /* side by side while every stream can refill a whole word and has four symbols to go */
+        quads = cnt[3] / 4;
+        for (q = 0; q < quads; q++) {
+            int j;
+            if (!(hufrd_fast(&r[0]) && hufrd_fast(&r[1]) && hufrd_fast(&r[2]) && hufrd_fast(&r[3]))) break;
+            hufrd_reload_fast(&r[0]); hufrd_reload_fast(&r[1]); hufrd_reload_fast(&r[2]); hufrd_reload_fast(&r[3]);
+            for (j = 0; j < 4; j++) {                                         /* used <= 7 + 4 * 12 < 64 throughout */
+                const u32 e0 = dt[(u32)((r[0].c << r[0].used) >> shift)], e1 = dt[(u32)((r[1].c << r[1].used) >> shift)];
+                const u32 e2 = dt[(u32)((r[2].c << r[2].used) >> shift)], e3 = dt[(u32)((r[3].c << r[3].used) >> shift)];
+                o[0][4 * q + (size_t)j] = (u8)e0; r[0].used += e0 >> 8;
+                o[1][4 * q + (size_t)j] = (u8)e1; r[1].used += e1 >> 8;
+                o[2][4 * q + (size_t)j] = (u8)e2; r[2].used += e2 >> 8;
+                o[3][4 * q + (size_t)j] = (u8)e3; r[3].used += e3 >> 8;
             }
-#undef REFILL
-            if (remaining != 0) return 0;
+        }
+        done[0] = done[1] = done[2] = done[3] = 4 * q;
+        /* the rest of every stream, one symbol at a time; below the start a stream reads as zeros, and a stream that is not used up
+         * exactly is corrupt (BIT_endOfDStream, huf_decompress.c:197-199) */
+        for (k = 0; k < 4; k++) {
+            size_t i;
+            for (i = done[k]; i < cnt[k]; i++) {
+                u32 e;
+                hufrd_reload(&r[k]);
+                if (r[k].used >= 64) return 0;                                /* nothing left to read a symbol from */
+                e = dt[(u32)((r[k].c << r[k].used) >> shift)];
+                o[k][i] = (u8)e;
+                r[k].used += e >> 8;
+            }
+            hufrd_reload(&r[k]);
+            if (!(r[k].ptr == r[k].start && r[k].used == 64)) return 0;
         }
     }
     return 1;
@@ -304,13 +344,18 @@ static int len_ext(const u8** pp, const u8* end, size_t* value)
 
 /* out[op..op+ml) = the bytes `off` back, LZ semantics; the source may lie in the prefix, in the external dictionary, or straddle
  * both (lizard_decompress_lz4.h:112-133).  0 = offset outside the history. */
+/* n bytes in steps of 16 / 8, writing (and reading) up to 15 / 7 bytes past the end: every caller has checked the reference's
+ * WILDCOPYLENGTH margins (16 bytes of room behind the copy in the output, and behind the literals in their stream) */
+static void wild16(u8* d, const u8* s, size_t n) { u8* const e = d + n; do { memcpy(d, s, 16); d += 16; s += 16; } while (d < e); }
+static void wild8(u8* d, const u8* s, size_t n)  { u8* const e = d + n; do { memcpy(d, s, 8); d += 8; s += 8; } while (d < e); }
+
 static int copy_match(const Env* e, u8* op, size_t off, size_t ml)
 {
     const size_t back = (size_t)(op - e->prefixStart);                        /* contiguous bytes available behind op */
     if (off <= back) {
         const u8* m = op - off;
-        if (off >= ml) memcpy(op, m, ml);
-        else if (off >= 8) { size_t i = 0; for (; i + 8 <= ml; i += 8) memcpy(op + i, m + i, 8); for (; i < ml; i++) op[i] = m[i]; }
+        if (off >= 16) wild16(op, m, ml);                                     /* (ml >= 3; room: ml <= oend - op - WILDCOPYLENGTH) */
+        else if (off >= 8) wild8(op, m, ml);
         else { size_t i; for (i = 0; i < ml; i++) op[i] = m[i]; }
         return 1;
     }
@@ -347,7 +392,7 @@ static long decode_lz4(const Env* e, Streams* s, u8* const dest, size_t cap)
             L += 15;
         }
         if ((long)L > (long)(oend - op) - LZH_WILD || (long)L > (long)(iend - lp) - (2 + LZH_WILD)) return -1;   /* :63 */
-        memcpy(op, lp, L);
+        if (L) wild16(op, lp, L);                                             /* (both margins just checked) */
         op += L; lp += L;
         if (e->partial && op >= oexit) return (long)(op - dest);              /* :77 */
         off = le16(lp); lp += 2;                                              /* :80-81 */
@@ -394,7 +439,8 @@ static long decode_lizv1(const Env* e, Streams* s, u8* const dest, size_t cap)
                 L += 7;
             }
             if ((long)L > (long)(oend - op) - LZH_WILD || (long)(iend - lp) < LZH_WILD || L > (size_t)(iend - lp)) return -1;   /* :81 */
-            memcpy(op, lp, L);
+            if (L + LZH_WILD <= (size_t)(iend - lp)) { if (L) wild16(op, lp, L); }
+            else memcpy(op, lp, L);
             op += L; lp += L;
             if ((token >> 7) == 0) {                                          /* :96-110 a new 16-bit offset */
                 if (s->o16End - s->o16 < 2) return -1;
