@@ -266,6 +266,54 @@ def test_emulated_hashchain_searches_decided_ahead_of_the_parse():
             assert from_table == 0 and searched > 0, (level, from_table)
 
 
+def test_emulated_hashchain_prepass_edges():
+    """The first-search table of levels 16/17/37/38 (lz_hc_hits) compares 16 bytes per candidate: inputs whose matches end exactly
+    at, just before and just after those 16 bytes, at every distance from the end of a sub-block and of the block (where the room
+    of a match shrinks to nothing and the second 8-byte load is clamped), tiny blocks, and candidates more than four deep."""
+    rnd = random.Random(16)
+    phrase = bytes(rnd.randrange(256) for _ in range(40))
+    cases = []
+    for n in list(range(8, 72)) + [100, 131072 - 30, 131072 - 17, 131072 - 1, 131072, 131072 + 1, 131072 + 16, 131072 + 25, 262144 - 9, 262144]:
+        body = bytearray()
+        while len(body) < n:
+            k = rnd.choice((14, 15, 16, 17, 18, 23, 24, 25, 40))                 # shared prefix length of the next repeat
+            body += phrase[:k] + bytes([rnd.randrange(256)])
+            if rnd.randrange(4) == 0:
+                body += bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 30)))
+        cases.append(bytes(body[:n]))
+    deep = (b"abcdefgh" + bytes(8)) * 6 + b"".join(b"abcd" + bytes([i]) * 5 for i in range(40)) + b"abcdefghijklmnopqrstuvwxyz" * 3   # many candidates per 4-byte hash
+    cases += [deep, deep * 9]
+    for i, data in enumerate(cases):
+        for level in (16, 17, 37):
+            if len(data) > 100000 and level != 16 + (i % 2):
+                continue
+            assert emul_compress(data, level, 1 + i % 4) == util.oracle_compress(data, level), (i, len(data), level)
+
+
+def test_emulated_pricefast_chained_edges():
+    """Chained priceFast rounds: matches that end exactly at, just before and just after the 24 fetched bytes (resolved / unresolved
+    lengths), sequences that end at lanes 62-65 of their round (the chain must stop at the round's edge), repeats at distances
+    below MIN_OFFSET, the same offset again and again (repeat-offset matches inside a chain), and every distance from the end of a
+    sub-block — all three table forms."""
+    rnd = random.Random(21)
+    phrase = bytes(rnd.randrange(256) for _ in range(64))
+    cases = []
+    for n in (40, 64, 65, 127, 128, 129, 4000, 131072 - 21, 131072 - 20, 131072 - 19, 131072 - 1, 131072, 131072 + 1, 131072 + 23, 150000):
+        body = bytearray()
+        while len(body) < n:
+            kind = rnd.randrange(6)
+            if kind == 0:   body += phrase[:rnd.choice((22, 23, 24, 25, 26, 31, 32, 33))] + bytes([rnd.randrange(256)])
+            elif kind == 1: body += bytes(rnd.randrange(256) for _ in range(rnd.choice((1, 2, 3, 5, 37, 57, 58, 59, 60, 61))))     # push sequence ends around lane 63
+            elif kind == 2: body += bytes([rnd.randrange(256)]) * rnd.choice((3, 7, 8, 9, 30))                                    # runs: distances below MIN_OFFSET
+            elif kind == 3: body += (phrase[5:12] + bytes([len(body) & 255])) * rnd.choice((2, 3, 9))                              # one offset again and again
+            elif kind == 4: body += phrase[rnd.randrange(30):][:rnd.randrange(4, 20)]
+            else:           body += body[-rnd.randrange(1, 200):][:rnd.randrange(4, 70)] if body else b"x"
+        cases.append(bytes(body[:n]))
+    for i, data in enumerate(cases):
+        for level, seed in ((21, 1), (21, 2), (21, 4), (41, 1 + i % 4), (22, 1 + i % 2)):
+            assert emul_compress(data, level, seed) == util.oracle_compress(data, level), (i, len(data), level, seed)
+
+
 def test_emulated_pricefast_chained_paths_are_reached():
     """Levels 21 / 41 / 22 take several sequences out of one round and run the lazy step (pricefast.h:184-228) from the lanes'
     registers (lz_pricefast.h, "several sequences out of one round").  The emulator counts the parser's LZ_STAT marks: every exit
