@@ -13,6 +13,7 @@
 #include <string.h>
 #include <algorithm>
 #include <atomic>
+#include <dlfcn.h>
 #include <thread>
 #include <vector>
 
@@ -101,6 +102,11 @@ int main(int argc, char** argv)
     else snprintf(verdict, sizeof verdict, "ok (sample of %zu)", nver < nb ? nver : nb);
     printf("L%d %zu x %zu: kernel %.3f ms  %.2f GB/s input  ratio %.4f  compressed %llu  verify %s\n", level, nb, bs, ms,
            (double)nb * bs / (ms * 1e-3) / 1e9, (double)nb * bs / (double)tot, tot, verdict);
+    {   // instrumented library variants only (LD_LIBRARY_PATH=lizard_amd/variants/<a -DLZ_PROFILE build>): phase clocks summed over the waves
+        int (*dump)(unsigned long long*) = (int (*)(unsigned long long*))dlsym(RTLD_DEFAULT, "LizardGPU_profileDump");
+        unsigned long long pr[16];
+        if (dump && dump(pr) == 0) { printf("    prof raw (all launches):"); for (int k = 0; k < 15; k++) printf(" [%d]=%.4g", k, (double)pr[k]); printf("\n"); }
+    }
     if (argc > 7 && argv[7][0] == 'd') {                     // decompress the batch back (slot layout) and compare a sample with the input
         unsigned char* back = nullptr; uint32_t* osz = nullptr;
         CK(hipMalloc((void**)&back, nb * bs)); CK(hipMalloc((void**)&osz, nb * 4));
