@@ -226,7 +226,55 @@ def cpu_baseline(L, level, block_size, n_blocks, budget_s, seed0=0, whole_buffer
             else f"first {n_blocks} blocks x {block_size} B of rank 0's workload")
     return {"value": round(nbytes / best / 1e6, 1), "unit": "MB/s", "cores": 1, "kind": kind,
             "sample": f"{what}, level {level}, best of {loops} passes, 1 thread",
-            "ratio": round(nbytes / total_c, 4), "compressed_bytes": total_c, "host_cpus": os.cpu_count()}, buf
+            "ratio": round(nbytes / total_c, 4), "compressed_bytes": total_c, "host_cpus": os.cpu_count(), "host_cpu": host_cpu_model()}, buf
+
+
+def host_cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def reference_program_bench(hostbuf, levels, seconds=3):
+    """BASELINE configs[0] literally: the reference's OWN program — oracle/_ref/lizard_cli_ref, its
+    programs/*.c compiled against its own lib/ by oracle/Makefile — in benchmark mode on the same 64 MiB buffer the ctypes loop
+    above timed (programs/bench.c:231-255: blocks of -B bytes through Lizard_compress one after the other, fastest loop of -i
+    seconds, MB = 10^6 B, :321-328 the result line).  Absent binary (it is git-ignored and built where /root/reference exists):
+    says so.  One thread, like every run of the reference."""
+    import re
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "lizard_cli_ref")
+    if not os.path.exists(exe):
+        return {"note": "oracle/_ref/lizard_cli_ref not present (built by oracle/Makefile where /root/reference exists)"}
+    res = {"program": "oracle/_ref/lizard_cli_ref (the reference's programs/ + lib/, unmodified, -O3)", "host_cpu": host_cpu_model(),
+           "host_cpus": os.cpu_count(), "threads": 1, "levels": []}
+    with tempfile.NamedTemporaryFile(prefix="lizard_bench_p50_", suffix=".bin", dir="/tmp", delete=False) as f:
+        f.write(hostbuf.raw)
+        path = f.name
+    try:
+        for lv in levels:
+            cmd = [exe, f"-b{lv}", f"-e{lv}", "-B262144", f"-i{seconds}", "-q", path]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+            except subprocess.TimeoutExpired:
+                res["levels"].append({"level": lv, "error": "timeout"})
+                continue
+            # "-10    40533852 (1.656) 690.12 MB/s 2873.8 MB/s  name"
+            m = re.search(r"-%d\s+(\d+)\s+\(([\d.]+)\)\s+([\d.]+) MB/s\s+([\d.]+) MB/s" % lv, (r.stdout + r.stderr).replace("\r", "\n"))
+            if not m:
+                res["levels"].append({"level": lv, "error": "could not parse the program's output", "output": (r.stdout + r.stderr)[-200:]})
+                continue
+            res["levels"].append({"level": lv, "command": " ".join(cmd[:-1]) + " <64 MiB RDG_genBuffer P50 seed 0>", "compressed_bytes": int(m.group(1)),
+                                  "ratio": float(m.group(2)), "compress_MB_s": float(m.group(3)), "decompress_MB_s": float(m.group(4))})
+    finally:
+        os.unlink(path)
+    return res
 
 
 def verify_all_blocks(L, level, bs, nb, src, dst, sizes, stride, seed0, byte_blocks, threads):
@@ -388,6 +436,17 @@ def main():
         _lib.check(L.LizardGPU_commInitRank(bytes(128), world, rank), "LizardGPU_commInitRank")
         gather_via = (f"library: LizardGPU_gatherSizes_device over a transport installed with LizardGPU_setCollectives — "
                       f"host bounce (hipMemcpy + torch.distributed gloo), {world} ranks on {ndev} device(s); functional check, not a scaling measurement")
+    comm_info = None
+    if world > 1:
+        info = (ctypes.c_int * 6)()
+        L.LizardGPU_commInfo(info)
+        comm_info = {"transport": "rccl" if info[0] == 0 else "LizardGPU_setCollectives table", "ranks_requested": info[1],
+                     "rccl_ranks_seen": info[2], "rccl_rank_seen": info[3], "rccl_version": info[4]}
+        # the line must not quote an N-GPU figure unless the transport itself saw N ranks
+        if transport == "rccl" and info[2] != world:
+            raise SystemExit(f"bench.py rank {rank}: --gpus {world} but the library's RCCL communicator reports {info[2]} ranks")
+        if info[1] != world:
+            raise SystemExit(f"bench.py rank {rank}: --gpus {world} but the library's rank communicator was made for {info[1]} ranks")
 
     if args.level is not None:
         plan = [(args.level, args.block_size, args.blocks or 16384)]
@@ -548,7 +607,10 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": head["workload"], "level": head["level"], "block_size": head["block_size"],
                        "blocks_per_gpu": head["blocks_per_gpu"], "resident_waves": int(L.LizardGPU_residentWaves()),
-                       "size_gather": state["gather"]},
+                       "size_gather": state["gather"], "size_gather_transport": comm_info,
+                       "scaling_note": ("weak scaling: every GPU compresses blocks_per_gpu blocks of its own (BASELINE configs[4], 4 MiB "
+                                        "frame blocks over 8 GPUs, runs as configs[] entry 'level 10 x 4 MiB' at 6 656 blocks PER GPU = two "
+                                        "per table-holding wave; a launch needs >= 3 328 blocks to fill one MI355X)")},
             "ratio": head["ratio"], "compressed_bytes": head["compressed_bytes"],
             "roofline": head["roofline"],
         }
@@ -605,6 +667,7 @@ def main():
                 dt = time.perf_counter() - t0
                 best = dt if best is None else min(best, dt)
             c1["gpu_MB_s_same_buffer_host_to_host"] = round(256 * 262144 / best / 1e6, 1)
+            c1["reference_program"] = reference_program_bench(hostbuf, (10, 21, 30))
             out["config1"] = c1
             # N host threads in the reference's ONE-BLOCK entry point at once (the combiner): tests/gpu_threads.c, every call checked
             exe = os.path.join(ROOT, "tests", "gpu_threads")

@@ -289,6 +289,17 @@ typedef struct {
 } LizardGPU_Collectives;
 int  LizardGPU_setCollectives(const LizardGPU_Collectives* table);
 int  LizardGPU_rcclShared(void);
+/* What carries the size exchange of this process, as the transport itself reports it — a figure measured over N ranks can say
+ * whether RCCL saw N ranks.  LizardGPU_commInitRank and the communicators of LizardGPU_compressBlocks_sharded are checked against
+ * ncclCommCount / ncclCommUserRank when they are made (a mismatch fails the call with -LIZARDGPU_ERR_RCCL).
+ *   info[0]  0 = RCCL, 1 = a table installed with LizardGPU_setCollectives
+ *   info[1]  ranks the caller asked for in LizardGPU_commInitRank (0 = no rank communicator)
+ *   info[2]  ranks the RCCL rank communicator reports (ncclCommCount; 0 = none, -1 = this RCCL does not export the call)
+ *   info[3]  this process's rank as RCCL reports it (ncclCommUserRank; -1 = n/a)
+ *   info[4]  ncclGetVersion (0 = RCCL not loaded)
+ *   info[5]  ranks of the single-process communicators of LizardGPU_compressBlocks_sharded (0 = none)
+ * Always returns 0. */
+int  LizardGPU_commInfo(int info[6]);
 
 /* ---- decompression ----
  * Independent blocks as Lizard_decompress_safe() decodes them (reference lib/lizard_decompress.h:64, lizard_decompress.c:267;

@@ -246,9 +246,9 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
     // one, or — all busy, none left to make — the extra ones in turn.
     LzArena* ar = nullptr;                                                   // nullptr: the context's own
     const bool smallLaunch = nBlocks < (size_t)c.cus * perGroup;
-    if (smallLaunch && !hcLevel && c.maxArenas > 1 && c.timed && c.lastStream != stream && hipEventQuery(c.ev1) == hipErrorNotReady) {
+    if (smallLaunch && !hcLevel && c.maxArenas > 1 && c.timed && c.lastStream != stream && hipEventQuery(c.ev1) != hipSuccess) {
         for (int i = 0; i < c.nExtra && !ar; i++) if (c.extra[i].lastStream == stream) ar = &c.extra[i];
-        for (int i = 0; i < c.nExtra && !ar; i++) if (!c.extra[i].timed || hipEventQuery(c.extra[i].ev1) == hipSuccess) ar = &c.extra[i];
+        for (int i = 0; i < c.nExtra && !ar; i++) if (!c.extra[i].timed || hipEventQuery(c.extra[i].ev1) == hipSuccess) ar = &c.extra[i];   // (anything but success: busy)
         if (!ar && c.nExtra < c.maxArenas - 1) {
             LzArena& x = c.extra[c.nExtra];
             memset(&x, 0, sizeof x);
@@ -327,7 +327,9 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
     // The scratch arena, the tables and the block counter are shared by all launches on this device: a launch
     // on another stream first waits (on the GPU) for the previous one to finish.
     hipEvent_t const e0 = ar ? ar->ev0 : c.ev0, e1 = ar ? ar->ev1 : c.ev1;
-    if (ar ? (ar->timed && ar->lastStream != stream) : (c.timed != 0)) LZ_HIP(hipStreamWaitEvent(stream, e1, 0));
+    // (always, also on the stream that used the arena last: a destroyed stream's handle can come back for a new stream, and a
+    //  same-stream wait costs nothing)
+    if (ar ? ar->timed != 0 : c.timed != 0) LZ_HIP(hipStreamWaitEvent(stream, e1, 0));
     LZ_HIP(hipMemsetAsync(a.counter, 0, 4, stream));
     LZ_HIP(hipEventRecord(e0, stream));
     if (k0) LZ_HIP(hipEventRecord(k0, stream));

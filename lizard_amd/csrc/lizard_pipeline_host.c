@@ -407,7 +407,9 @@ typedef struct LzOneJob {
     struct LzOneJob* next;
 } LzOneJob;
 enum { JOB_QUEUED = 0, JOB_COPY_IN, JOB_COPIED_IN, JOB_RESULT, JOB_FAILED };
-#define LZ_ONE_MAX_JOBS   1024                  /* members per batch */
+#ifndef LZ_ONE_MAX_JOBS
+#define LZ_ONE_MAX_JOBS   1024                  /* members per batch (tests build a library with 3: lizard_amd/csrc/Makefile combiner-test) */
+#endif
 #define LZ_ONE_MAX_BYTES  ((size_t)1 << 30)     /* input bytes per batch */
 #ifndef LZ_ONE_WINDOW_US
 #define LZ_ONE_WINDOW_US  150L                  /* longest a leader waits for the stragglers of the previous batch */
@@ -544,11 +546,15 @@ static void lead_batch(LzCtx* c, LzOneJob* mine)
         while (k->queued < k->lastN && pthread_cond_timedwait(&k->cv, &k->mu, &until) == 0) {}
         k->collecting = 0;
     }
-    /* members: my job and every queued job of my level, in arrival order, while they fit; the others stay queued */
+    /* members: my job FIRST (the leader is always a member of the batch it leads, however many callers are queued in front of
+     * it), then every queued job of my level, in arrival order, while they fit; the others stay queued */
+    mine->inOff = 0; inBytes = maxSize = (size_t)mine->srcSize;
+    jobs[n++] = mine;
     for (j = k->head; j; ) {
         LzOneJob* const next = j->next;
         const size_t at = (inBytes + 255) & ~(size_t)255;
-        if (j->level == level && n < LZ_ONE_MAX_JOBS && (j == mine || at + (size_t)j->srcSize <= LZ_ONE_MAX_BYTES)) {
+        if (j == mine) { j->next = NULL; j = next; continue; }              /* (already a member: leaves the queue) */
+        if (j->level == level && n < LZ_ONE_MAX_JOBS && at + (size_t)j->srcSize <= LZ_ONE_MAX_BYTES) {
             j->inOff = at; inBytes = at + (size_t)j->srcSize;
             if ((size_t)j->srcSize > maxSize) maxSize = (size_t)j->srcSize;
             jobs[n++] = j;
@@ -566,6 +572,11 @@ static void lead_batch(LzCtx* c, LzOneJob* mine)
 
     lzk_guard_acquire(&g);                      /* context lock + this device current */
     rc = g.rc;
+    if (!rc && g.c != c) {                      /* another thread moved the process default device since this caller queued: the batch's
+                                                 * buffers and stream belong to `c`, whose lock this is not — fail the batch, touch nothing */
+        snprintf(lzk_err(), LZK_ERR_BYTES, "the selected device changed while a batch of one-block calls was forming");
+        rc = -LIZARDGPU_ERR_ARG;
+    }
     if (!rc) rc = batch_buffers(c, n, inBytes, maxSize);
     t1 = t2 = now_s();
     if (!rc) {

@@ -29,6 +29,9 @@ struct Rccl {
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;       // optional
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;      // optional: what the communicator itself says it spans
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;   // optional
+    ncclResult_t (*GetVersion)(int*) = nullptr;            // optional
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -44,6 +47,8 @@ int        g_allDevs[LZ_MAX_DEVICES];
 int        g_allCount = 0;
 ncclComm_t g_rankComm = nullptr;
 int        g_rankCount = 0, g_rankIndex = -1;
+int        g_rankSeen = 0, g_rankSeenIndex = -1;           // what the communicator reports after its creation (ncclCommCount / ncclCommUserRank)
+int        g_allSeen = 0;                                  // ncclCommCount of the single-process communicators (0 = none / not reported)
 // the transport of the size exchange: RCCL unless LizardGPU_setCollectives installed another one
 LzCollectives g_userCol;
 bool          g_haveUserCol = false;
@@ -65,6 +70,9 @@ int rccl_load()
     LZ_SYM(GroupStart, "ncclGroupStart"); LZ_SYM(GroupEnd, "ncclGroupEnd"); LZ_SYM(GetErrorString, "ncclGetErrorString");
 #undef LZ_SYM
     *(void**)(&g_rccl.CommAbort) = dlsym(so, "ncclCommAbort");
+    *(void**)(&g_rccl.CommCount) = dlsym(so, "ncclCommCount");
+    *(void**)(&g_rccl.CommUserRank) = dlsym(so, "ncclCommUserRank");
+    *(void**)(&g_rccl.GetVersion) = dlsym(so, "ncclGetVersion");
     g_rccl.so = so; g_rccl.shared = shared;
     return 0;
 }
@@ -73,6 +81,19 @@ int nccl_fail(const char* what, ncclResult_t r)
 {
     snprintf(t_err, sizeof t_err, "%s failed: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     return -LIZARDGPU_ERR_RCCL;
+}
+// Ask a fresh communicator what it spans: a job that believes it runs N ranks over RCCL while the communicator holds another
+// number must not report a scaling figure.  0 and *count / *rank filled (-1 where the library does not say), or an error.
+int rccl_verify(ncclComm_t comm, int wantCount, int wantRank, int* count, int* rank)
+{
+    *count = -1; *rank = -1;
+    if (g_rccl.CommCount) { const ncclResult_t r = g_rccl.CommCount(comm, count); if (r != ncclSuccess) return nccl_fail("ncclCommCount", r); }
+    if (g_rccl.CommUserRank) { const ncclResult_t r = g_rccl.CommUserRank(comm, rank); if (r != ncclSuccess) return nccl_fail("ncclCommUserRank", r); }
+    if ((*count >= 0 && *count != wantCount) || (*rank >= 0 && *rank != wantRank)) {
+        snprintf(t_err, sizeof t_err, "RCCL communicator reports rank %d of %d, expected rank %d of %d", *rank, *count, wantRank, wantCount);
+        return -LIZARDGPU_ERR_RCCL;
+    }
+    return 0;
 }
 // RCCL behind the collective table of lizard_shard_core.h
 int rccl_all_gather(const void* send, void* recv, size_t count, void* comm, void* stream)
@@ -130,7 +151,7 @@ void lz_shard_shutdown()
         for (int i = 0; i < g_allCount; i++) if (g_allComms[i]) (void)g_rccl.CommDestroy(g_allComms[i]);
         if (g_rankComm) (void)g_rccl.CommDestroy(g_rankComm);
     }
-    g_allCount = 0; g_rankComm = nullptr; g_rankCount = 0; g_rankIndex = -1;
+    g_allCount = 0; g_rankComm = nullptr; g_rankCount = 0; g_rankIndex = -1; g_rankSeen = 0; g_rankSeenIndex = -1; g_allSeen = 0;
     pthread_mutex_unlock(&g_rccl_mu);
 }
 
@@ -190,7 +211,12 @@ int LizardGPU_compressBlocks_sharded(int nDevices, const int* devices, const voi
             g_allCount = 0;
             const ncclResult_t r_ = g_rccl.CommInitAll(g_allComms, nDevices, devs);
             if (r_ != ncclSuccess) rc = nccl_fail("ncclCommInitAll", r_);
-            else { g_allCount = nDevices; memcpy(g_allDevs, devs, sizeof(int) * (size_t)nDevices); }
+            else {
+                g_allCount = nDevices; memcpy(g_allDevs, devs, sizeof(int) * (size_t)nDevices);
+                g_allSeen = 0;
+                for (int r = 0; r < nDevices && !rc; r++) { int cnt, rk; rc = rccl_verify(g_allComms[r], nDevices, r, &cnt, &rk); if (!rc && cnt > 0) g_allSeen = cnt; }
+                if (rc) abort_all_comms();
+            }
         }
     }
     const int savedSel = t_device;
@@ -259,13 +285,16 @@ int LizardGPU_commInitRank(const void* id128, int nRanks, int rank)
         if (!rc && g_haveUserCol) {
             // a transport installed with LizardGPU_setCollectives needs no RCCL communicator: the rank index is what it is handed as `comm`
             if (g_rankComm && g_rccl.so) (void)g_rccl.CommDestroy(g_rankComm);
-            g_rankComm = nullptr; g_rankCount = nRanks; g_rankIndex = rank;
+            g_rankComm = nullptr; g_rankCount = nRanks; g_rankIndex = rank; g_rankSeen = 0; g_rankSeenIndex = -1;
         } else if (!rc && !(rc = rccl_load())) {
             if (g_rankComm) { (void)g_rccl.CommDestroy(g_rankComm); g_rankComm = nullptr; }
             ncclUniqueId id;
             memcpy(&id, id128, sizeof id);
             const ncclResult_t r_ = g_rccl.CommInitRank(&g_rankComm, nRanks, id, rank);
             if (r_ != ncclSuccess) { g_rankComm = nullptr; g_rankCount = 0; g_rankIndex = -1; rc = nccl_fail("ncclCommInitRank", r_); }
+            else if ((rc = rccl_verify(g_rankComm, nRanks, rank, &g_rankSeen, &g_rankSeenIndex))) {
+                (void)g_rccl.CommDestroy(g_rankComm); g_rankComm = nullptr; g_rankCount = 0; g_rankIndex = -1;
+            }
             else { g_rankCount = nRanks; g_rankIndex = rank; }
         }
     }
@@ -292,11 +321,28 @@ int LizardGPU_gatherSizes_device(const uint32_t* d_localSizes, size_t nBlocks, u
     return rc;
 }
 
+// What carries the size exchange of this process, as the transport itself reports it (bench.py puts it into its line so that an
+// N-GPU figure says whether RCCL saw N ranks).  info[0] = 0 RCCL / 1 a table installed with LizardGPU_setCollectives;
+// info[1] = ranks the caller asked for (LizardGPU_commInitRank, 0 = none); info[2] = ranks the RCCL communicator reports
+// (ncclCommCount; 0 = no RCCL communicator, -1 = this RCCL does not say); info[3] = this rank as RCCL reports it (ncclCommUserRank,
+// -1 = n/a); info[4] = ncclGetVersion (0 = RCCL not loaded / no such call); info[5] = ranks of the single-process communicators of
+// LizardGPU_compressBlocks_sharded (0 = none).  Always 0.
+int LizardGPU_commInfo(int info[6])
+{
+    pthread_mutex_lock(&g_rccl_mu);
+    int ver = 0;
+    if (g_rccl.so && g_rccl.GetVersion && g_rccl.GetVersion(&ver) != ncclSuccess) ver = 0;
+    info[0] = g_haveUserCol ? 1 : 0; info[1] = g_rankCount; info[2] = g_rankComm ? g_rankSeen : 0; info[3] = g_rankComm ? g_rankSeenIndex : -1;
+    info[4] = ver; info[5] = g_allCount ? g_allSeen : 0;
+    pthread_mutex_unlock(&g_rccl_mu);
+    return 0;
+}
+
 int LizardGPU_commDestroy(void)
 {
     pthread_mutex_lock(&g_rccl_mu);
     if (g_rccl.so && g_rankComm) (void)g_rccl.CommDestroy(g_rankComm);
-    g_rankComm = nullptr; g_rankCount = 0; g_rankIndex = -1;
+    g_rankComm = nullptr; g_rankCount = 0; g_rankIndex = -1; g_rankSeen = 0; g_rankSeenIndex = -1;
     pthread_mutex_unlock(&g_rccl_mu);
     return 0;
 }

@@ -11,6 +11,7 @@
 #   bash scripts/gpu_session.sh traffic <tag> "<level> <blockSize> <nBlocks>" ...     (scripts/gpu_traffic.sh)
 #   bash scripts/gpu_session.sh sq <tag> <variant|base> <level> <blockSize> <nBlocks>  (scripts/gpu_sq_counters.sh)
 MODE=$1; TAG=$2; shift; shift
+export LIZARD_REQUIRE_REF=1      # the reference-program GPU tests FAIL (not skip) when oracle/_ref did not travel
 R=$GRAFT_REPO_ROOT; cd $R; O=gpurun_out/$TAG; mkdir -p $O
 V=$R/lizard_amd/variants
 with_variant () { if [ "$1" != base ]; then export LD_LIBRARY_PATH=$V/$1; fi; }

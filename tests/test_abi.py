@@ -138,7 +138,7 @@ def test_reference_cli_runs_on_the_gpu_library(tmp_path):
     the CLI chose — i.e. every block really went through the GPU path and came out bit-exact."""
     exe = os.path.join(util.ROOT, "oracle", "_ref", "lizard_cli_amd")
     if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/lizard_cli_amd not built")
+        util.need_ref("oracle/_ref/lizard_cli_amd")
     data = util.datagen((9 << 20) + 12345, 0.5, 0.0, 17)
     (tmp_path / "in.bin").write_bytes(data)
     for level, extra in ((10, []), (30, ["-B1"]), (21, ["-B2"])):
@@ -162,7 +162,7 @@ def test_reference_cli_one_byte_tail_block(tmp_path):
     path must write the same .liz as the stock library (and as LizardGPU_compressFrame)."""
     exe = os.path.join(util.ROOT, "oracle", "_ref", "lizard_cli_amd")
     if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/lizard_cli_amd not built")
+        util.need_ref("oracle/_ref/lizard_cli_amd")
     for k, extra in ((2, ["-B1"]), (1, ["-B2"]), (0, [])):
         bs = {"-B1": 128 << 10, "-B2": 256 << 10}.get(extra[0] if extra else "", 4 << 20)
         data = util.datagen(k * bs + 1, 0.5, 0.0, 23 + k)
@@ -201,7 +201,7 @@ def test_reference_frametest_without_a_device_exercises_the_frame_state_machines
     if not os.path.exists(exe):
         util.reference()                                                     # builds oracle/_ref when the checkout is present
     if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/frametest_amd not built")
+        util.need_ref("oracle/_ref/frametest_amd")
     from lizard_amd import _lib
     _lib.build()
     for seed in (4242, 7254):
@@ -221,7 +221,7 @@ def test_reference_test_programs_on_the_gpu_library(prog, args, tmp_path):
     mode is served by history-free blocks (include/lizard_amd.h, Lizard_compress_continue)."""
     exe = os.path.join(util.ROOT, "oracle", "_ref", prog)
     if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/%s not built" % prog)
+        util.need_ref("oracle/_ref/%s" % prog)
     ldd = subprocess.check_output(["ldd", exe]).decode()
     assert "liblizard_amd.so" in ldd and "liblizard_ref" not in ldd
     undefined = subprocess.check_output(["nm", "-u", exe]).decode()
@@ -244,7 +244,7 @@ def test_liz_files_equal_the_stock_cli(tmp_path):
     amd = os.path.join(util.ROOT, "oracle", "_ref", "lizard_cli_amd")
     ref = os.path.join(util.ROOT, "oracle", "_ref", "lizard_cli_ref")
     if not (os.path.exists(amd) and os.path.exists(ref)):
-        pytest.skip("oracle/_ref CLIs not built")
+        util.need_ref("oracle/_ref CLIs")
     data = util.datagen((5 << 20) + 4321, 0.5, 0.0, 41)
     (tmp_path / "in.bin").write_bytes(data)
     for level, extra in ((10, []), (21, ["-B2"]), (30, ["-B1"]), (10, ["-B3", "--content-size"]), (30, ["--no-frame-crc"])):

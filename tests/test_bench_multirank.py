@@ -41,6 +41,11 @@ def test_bench_two_and_three_ranks_on_one_device(world, blocks):
     assert out["n_gpus"] == world and out["steps"] == 2 and out["warmup"] == 1
     assert out["config"]["blocks_per_gpu"] == blocks
     assert "host bounce" in out["config"]["size_gather"] and "LizardGPU_setCollectives" in out["config"]["size_gather"]
+    # the line says what carried the exchange and how many ranks it was made for (an RCCL job also says what RCCL itself saw,
+    # and bench.py refuses to print a line when that is not --gpus)
+    tr = out["config"]["size_gather_transport"]
+    assert tr["transport"] == "LizardGPU_setCollectives table" and tr["ranks_requested"] == world and tr["rccl_ranks_seen"] == 0
+    assert "weak scaling" in out["config"]["scaling_note"]
     assert [p["rank"] for p in out["per_rank"]] == list(range(world))
     assert all(p["kernel_ms"] > 0 and p["gather_us"] > 0 for p in out["per_rank"])
     assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["cores"] == 1

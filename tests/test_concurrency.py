@@ -137,3 +137,27 @@ def test_stream_churn_and_shutdown_under_load(lib):
     from lizard_amd import api
     blocks = api.compress_blocks(data[2] * 4, 262144, 10)
     assert blocks == [want[(2, 10)]] * 4
+
+
+@pytest.mark.gpu
+def test_leaders_with_more_callers_queued_than_a_batch_holds():
+    """The leader of a batch is always a member of it (round-4 advisor finding: with more same-level callers queued in front of a
+    waking leader than LZ_ONE_MAX_JOBS, the leader's job used to stay behind while its input was still copied to offset 0 of the
+    staging).  A library whose batches hold THREE members (lizard_amd/csrc/Makefile `combiner-test`, built by
+    __graft_entry__.build()) under 24 callers: every call compared with the oracle by tests/gpu_threads."""
+    import os
+    import subprocess
+    root = util.ROOT
+    var = os.path.join(root, "lizard_amd", "variants", "maxjobs3")
+    exe = os.path.join(root, "tests", "gpu_threads")
+    assert os.path.exists(os.path.join(var, "liblizard_amd.so")) and os.path.exists(exe), "run __graft_entry__.build() first"
+    env = dict(os.environ, LD_LIBRARY_PATH=var + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    for level, size in ((10, 65537), (21, 20000)):
+        r = subprocess.run([exe, "24", str(level), str(size), "1.5"], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines = [l for l in r.stdout.splitlines() if l.startswith("threads")]
+        assert lines and all("mismatches 0," in l for l in lines), r.stdout
+        # batches of three: at 24 threads a launch never carries more than 3 blocks
+        last = lines[-1].split()
+        launches, blocks = int(last[last.index("launches") - 1]), int(last[last.index("blocks") - 1])
+        assert blocks <= 3 * launches, lines[-1]

@@ -144,7 +144,7 @@ def test_stream_refusals_need_no_gpu(lib):
 def test_gpu_stream_equals_reference_stream(lib):
     ref = util.reference()
     if ref is None:
-        pytest.skip("oracle/_ref not present")
+        util.need_ref("oracle/_ref")
     rnd = random.Random(7)
     data = util.datagen(3 * (1 << 20) + 4321, 0.5, 0.0, 8) + bytes(200000) + rnd.randbytes(150000)
     for trial in range(14):

@@ -1,5 +1,5 @@
 """Multi-GPU side of the C library (include/lizard_amd.h, "several GPUs").
-CPU: the partition / offset code, agreement with the torch.distributed form (lizard_amd/sharding.py), and the library's
+CPU: the partition / offset code, agreement with the torch.distributed form (tests/torch_sharding.py), and the library's
 exchange logic itself (lizard_amd/csrc/lizard_shard_core.h) with 1..8 ranks, equal and ragged partitions, over a fake
 shared-memory transport (tests/shard_fake.cpp): the in-place all-gather, the per-root broadcasts, the grouped
 single-thread form and its error path.
@@ -30,7 +30,7 @@ def c_range(lib, n, r, w):
 
 
 def test_partition_is_contiguous_balanced_and_matches_python(lib):
-    from lizard_amd.sharding import shard_range
+    from torch_sharding import shard_range
     rnd = random.Random(3)
     for n, w in [(1, 1), (8, 8), (9, 8), (65536, 8), (65537, 8), (4096, 3), (7, 7)] + [(rnd.randrange(8, 10 ** 6), rnd.randrange(1, 9)) for _ in range(50)]:
         nxt = 0

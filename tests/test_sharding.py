@@ -10,7 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import util
-from lizard_amd.sharding import gather_block_sizes, shard_range
+from torch_sharding import gather_block_sizes, shard_range
 
 
 def test_shard_range_is_a_partition():

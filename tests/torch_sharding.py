@@ -1,4 +1,7 @@
-"""Multi-GPU sharding of independent Lizard blocks.
+"""TEST INFRASTRUCTURE: the torch.distributed twin of the library's size gather (lizard_amd/csrc/lizard_shard_core.h is the product's
+multi-GPU path; this form exists for the gloo world-size-2 CPU test and as the cross-check of the C partition code).
+
+Multi-GPU sharding of independent Lizard blocks.
 
 Blocks share nothing, so ranks own contiguous block ranges and the only exchange on the path is ONE
 all-gather of the per-block compressed sizes (uint32 per block), after which every rank computes the

@@ -74,6 +74,17 @@ def reference_datagen():
     return L
 
 
+def need_ref(what):
+    """A test needs a binary / library under oracle/_ref (git-ignored, built by oracle/Makefile where /root/reference exists and
+    carried to the GPU box by gpurun).  Absent: skip — or FAIL when LIZARD_REQUIRE_REF=1 (scripts/gpu_session.sh sets it: a GPU
+    session that silently skips the reference-program tests proves less than it seems to)."""
+    import pytest
+    msg = "%s not present (oracle/_ref is built by oracle/Makefile where /root/reference exists)" % what
+    if os.environ.get("LIZARD_REQUIRE_REF") == "1":
+        pytest.fail(msg + " and LIZARD_REQUIRE_REF=1")
+    pytest.skip(msg)
+
+
 _emul = None
 
 
