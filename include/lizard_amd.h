@@ -333,6 +333,29 @@ int LizardGPU_residentWaves(void);
  * Returns how many exist right now on the selected device (>= 1 once it was used; 0 before / without a device). */
 int LizardGPU_arenasInUse(void);
 
+/* Device memory.  A context (one per device) keeps a scratch arena (one slot per resident wave: 2.7 GB on a 256-CU device), and
+ * allocates on first use: up to three more arenas for small launches on concurrent streams (released again after 64 launches that
+ * did not need them), per-wave tables (levels 21/41: 256 MiB; 11/31/22/42: 4 GiB), hashChain work areas (levels 13-17 / 34-38: up
+ * to half of the free memory, at most 128 GiB), and the staging of the host-buffer entries (three chunks of 256 MiB in flight).
+ * LizardGPU_setMemoryBudget(bytes) bounds the sum per device (0 = no bound, the default): tables and work areas then get fewer
+ * slots than there are resident waves (fewer blocks in flight: slower, same bytes), what another level left behind is given up
+ * first, extra arenas are only made when they fit, host-buffer chunks shrink to bytes / 64; an allocation that still does not fit
+ * fails its call with -LIZARDGPU_ERR_NOMEM (Lizard_compress*: 0).  The call releases what every context holds (like
+ * LizardGPU_shutdown, communicators excepted) — set it before first use or between uses, not under load; below one scratch arena
+ * + 256 MiB it is refused (-LIZARDGPU_ERR_ARG, LizardGPU_lastError names the minimum).  The environment knobs stay
+ * (LIZARDGPU_ARENAS, LIZARDGPU_HC_WORKAREA_MB, LIZARDGPU_CHUNK_MB).
+ * LizardGPU_memoryInUse: bytes the selected device's context holds in those buffers.  LizardGPU_trim: gives back everything but the
+ * context's own scratch arena on the selected device (waits for the device to be idle). */
+int    LizardGPU_setMemoryBudget(size_t bytes);
+size_t LizardGPU_memoryBudget(void);
+size_t LizardGPU_memoryInUse(void);
+int    LizardGPU_trim(void);
+
+/* Calls of this process that could not compress on the GPU (level without a kernel, no device, HIP failure) and therefore returned
+ * 0 (Lizard_compress*) or stored their blocks raw (LizardF_compress*, non-strict): every one is counted here, and the 1st, 2nd,
+ * 4th, 8th ... prints one line on stderr with the reason.  The strict twins (LizardGPU_compressFrame ...) return an error instead. */
+unsigned long long LizardGPU_degradedCalls(void);
+
 /* The one-block entry points of part 1 (Lizard_compress, _extState, _continue) are COMBINED: callers that arrive while a launch is
  * in flight leave together in the next one — one ragged batch, one block per CU — instead of queueing behind a lock, so N host
  * threads compress N blocks per launch (lizard_amd/csrc/lizard_pipeline_host.c).  Launches made / blocks carried so far on the

@@ -211,7 +211,6 @@ static void raw_record(uint8_t* dst, const uint8_t* src, size_t n)
 static int frame_records(LizardF_compressionContext_t c, const uint8_t* src, size_t nb, size_t blockSize, size_t last,
                          uint8_t* dst, size_t cap, size_t reserve, size_t* written)
 {
-    static int warned = 0;
     const int onGpu = LizardGPU_levelSupported(c->level);
     size_t i, need;
     if (onGpu && lzgpu_frame_records(src, nb, blockSize, last, dst, cap, written, c->level) == 0) {
@@ -233,9 +232,7 @@ static int frame_records(LizardF_compressionContext_t c, const uint8_t* src, siz
             return 0;
         }
     }
-    if (!__atomic_exchange_n(&warned, 1, __ATOMIC_RELAXED))
-        fprintf(stderr, "liblizard_amd: frame blocks at level %d are stored uncompressed: %s (no CPU fallback in this library)\n", c->level,
-                onGpu ? LizardGPU_lastError() : "level not implemented on the GPU path");
+    lzgpu_note_degraded(onGpu ? "frame blocks are stored uncompressed: the GPU batch failed" : "frame blocks are stored uncompressed: level not implemented on the GPU path", c->level);
     need = (nb - 1) * (blockSize + 4) + last + 4;
     if (need > cap) return -1;
     for (i = 0; i < nb; i++) {

@@ -45,6 +45,28 @@ void set_err(const char* fmt, const char* a, const char* b)
         }                                                                                              \
     } while (0)
 
+// Memory budget (LizardGPU_setMemoryBudget): bytes of device memory the large buffers of ONE device's context may take (scratch
+// arenas, per-wave tables, hashChain work areas, the staging of the host-buffer entries); 0 = no cap.
+size_t g_budget = 0;
+size_t budget_room(const Ctx& c) { return !g_budget ? (size_t)-1 : (g_budget > c.devBytes ? g_budget - c.devBytes : 0); }
+int dev_alloc(Ctx& c, void** p, size_t bytes, const char* what)
+{
+    if (bytes > budget_room(c)) {
+        snprintf(t_err, sizeof t_err, "%s: %zu bytes do not fit the memory budget of %zu bytes (%zu in use; LizardGPU_setMemoryBudget)", what, bytes, g_budget, c.devBytes);
+        return -LIZARDGPU_ERR_NOMEM;
+    }
+    LZ_HIP(hipMalloc(p, bytes));
+    c.devBytes += bytes;
+    return 0;
+}
+void dev_free(Ctx& c, void* p, size_t bytes)
+{
+    if (!p) return;
+    (void)hipFree(p);
+    c.devBytes -= bytes < c.devBytes ? bytes : c.devBytes;
+}
+const size_t kScratchBytes = (size_t)LZ_MAX_WAVES * LZ_SCRATCH_BYTES;     // per CU
+
 int selected_device()
 {
     if (t_device >= 0) return t_device;
@@ -100,7 +122,7 @@ int ctx_init(Ctx& c)
     hipDeviceProp_t prop;
     LZ_HIP(hipGetDeviceProperties(&prop, c.device));
     c.cus = prop.multiProcessorCount;
-    LZ_HIP(hipMalloc((void**)&c.scratch, (size_t)c.cus * LZ_MAX_WAVES * LZ_SCRATCH_BYTES));   // one slot per resident wave (one workgroup per CU)
+    { const int rc_ = dev_alloc(c, (void**)&c.scratch, (size_t)c.cus * kScratchBytes, "scratch arena"); if (rc_) return rc_; }   // one slot per resident wave (one workgroup per CU)
 #ifdef LZ_PROFILE
     LZ_HIP(hipMemset(c.scratch, 0, (size_t)c.cus * LZ_MAX_WAVES * LZ_SCRATCH_BYTES));
 #endif
@@ -180,6 +202,46 @@ void ctx_release(Ctx& c)
     if (c.ev1) (void)hipEventDestroy(c.ev1);
     c.tables = c.pfTables = c.hcSlots = c.scratch = nullptr; c.counter = nullptr; c.hcMaxBlock = 0;
     c.ev0 = c.ev1 = c.lastEv0 = c.lastEv1 = nullptr; c.timed = 0; c.laneOrderOk = 1; c.ready = 0;
+    c.tablesSlots = c.pfSlots = 0; c.devBytes = 0; c.idleLaunches = 0;
+}
+
+void free_extra_arenas(Ctx& c)                                   // (their launches have finished: caller's business)
+{
+    for (int i = 0; i < c.nExtra; i++) {
+        LzArena& x = c.extra[i];
+        dev_free(c, x.scratch, (size_t)c.cus * kScratchBytes);
+        if (x.counter) (void)hipFree(x.counter);
+        dev_free(c, x.tables, x.tablesSlots * LZ_TABWIDE_BYTES(18));
+        dev_free(c, x.pfTables, x.pfSlots * LZ_PF_SLOT_BYTES);
+        if (x.ev0) (void)hipEventDestroy(x.ev0);
+        if (x.ev1) (void)hipEventDestroy(x.ev1);
+        memset(&x, 0, sizeof x);
+    }
+    c.nExtra = 0; c.nextExtra = 0;
+}
+// Everything but the context's own arena: extra arenas, per-wave tables, hashChain work areas (`keep`: 0 none, 1 tables, 2 pfTables,
+// 3 hcSlots).  The device is idle afterwards (synchronised first: other launches may still be using what is freed).
+void free_tables_except(Ctx& c, int keep)
+{
+    (void)hipDeviceSynchronize();
+    free_extra_arenas(c);
+    if (keep != 1 && c.tables) { dev_free(c, c.tables, c.tablesSlots * LZ_TABWIDE_BYTES(18)); c.tables = nullptr; c.tablesSlots = 0; }
+    if (keep != 2 && c.pfTables) { dev_free(c, c.pfTables, c.pfSlots * LZ_PF_SLOT_BYTES); c.pfTables = nullptr; c.pfSlots = 0; }
+    if (keep != 3 && c.hcSlots) { dev_free(c, c.hcSlots, c.hcNSlots * c.hcSlotBytes); c.hcSlots = nullptr; c.hcNSlots = 0; c.hcMaxBlock = 0; c.hcHasBest = 0; c.hcSlotBytes = 0; }
+}
+// Per-wave table slots of `stride` bytes under the budget: as many as resident waves if they fit — after giving up what other
+// levels left behind, if need be — else as many as fit (the waves without one leave, lz_wave_main); none: out of memory.
+int alloc_table_slots(Ctx& c, uint8_t** at, size_t* slotsAt, size_t stride, int kind, bool ownArena, const char* what)
+{
+    const size_t want = (size_t)c.cus * LZ_MAX_WAVES;
+    if (want * stride > budget_room(c) && ownArena) free_tables_except(c, kind);
+    size_t slots = budget_room(c) / stride;
+    if (slots > want) slots = want;
+    if (!slots) { snprintf(t_err, sizeof t_err, "%s: not one table of %zu bytes fits the memory budget of %zu bytes (%zu in use)", what, stride, g_budget, c.devBytes); return -LIZARDGPU_ERR_NOMEM; }
+    const int rc = dev_alloc(c, (void**)at, slots * stride, what);
+    if (rc) return rc;
+    *slotsAt = slots;
+    return 0;
 }
 
 int clamp_level(int level)                                       // reference lizard_compress.c:303-308
@@ -249,10 +311,11 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
     if (smallLaunch && !hcLevel && c.maxArenas > 1 && c.timed && c.lastStream != stream && hipEventQuery(c.ev1) != hipSuccess) {
         for (int i = 0; i < c.nExtra && !ar; i++) if (c.extra[i].lastStream == stream) ar = &c.extra[i];
         for (int i = 0; i < c.nExtra && !ar; i++) if (!c.extra[i].timed || hipEventQuery(c.extra[i].ev1) == hipSuccess) ar = &c.extra[i];   // (anything but success: busy)
-        if (!ar && c.nExtra < c.maxArenas - 1) {
+        if (!ar && c.nExtra < c.maxArenas - 1 && budget_room(c) >= (size_t)c.cus * kScratchBytes) {
             LzArena& x = c.extra[c.nExtra];
             memset(&x, 0, sizeof x);
-            hipError_t e = hipMalloc((void**)&x.scratch, (size_t)c.cus * LZ_MAX_WAVES * LZ_SCRATCH_BYTES);
+            hipError_t e = hipMalloc((void**)&x.scratch, (size_t)c.cus * kScratchBytes);
+            if (e == hipSuccess) c.devBytes += (size_t)c.cus * kScratchBytes;
             if (e == hipSuccess) e = hipMalloc((void**)&x.counter, 64);
             if (e == hipSuccess) e = hipEventCreate(&x.ev0);
             if (e == hipSuccess) e = hipEventCreate(&x.ev1);
@@ -261,7 +324,7 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
                 if (getenv("LIZARDGPU_VERBOSE")) fprintf(stderr, "liblizard_amd: device %d: arena %d for small launches on concurrent streams (LIZARDGPU_ARENAS caps them)\n", c.device, c.nExtra + 1);
             } else {                                                         // no room: share the context's own after all
                 (void)hipGetLastError();
-                if (x.scratch) (void)hipFree(x.scratch);
+                dev_free(c, x.scratch, (size_t)c.cus * kScratchBytes);
                 if (x.counter) (void)hipFree(x.counter);
                 if (x.ev0) (void)hipEventDestroy(x.ev0);
                 if (x.ev1) (void)hipEventDestroy(x.ev1);
@@ -271,8 +334,19 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
         if (!ar && c.nExtra) { ar = &c.extra[c.nextExtra % c.nExtra]; c.nextExtra++; }
         (void)hipGetLastError();                                             // (hipEventQuery's "not ready" is not an error to report)
     }
+    // extra arenas that no launch has asked for in a while go back (64 launches on the context's own arena, all of theirs finished)
+    if (ar) c.idleLaunches = 0;
+    else if (c.nExtra && ++c.idleLaunches >= 64) {
+        bool idle = true;
+        for (int i = 0; i < c.nExtra; i++) if (c.extra[i].timed && hipEventQuery(c.extra[i].ev1) != hipSuccess) idle = false;
+        (void)hipGetLastError();
+        if (idle) free_extra_arenas(c);
+        c.idleLaunches = 0;
+    }
     uint8_t** const tablesAt = ar ? &ar->tables : &c.tables;
     uint8_t** const pfTablesAt = ar ? &ar->pfTables : &c.pfTables;
+    size_t* const tablesSlotsAt = ar ? &ar->tablesSlots : &c.tablesSlots;
+    size_t* const pfSlotsAt = ar ? &ar->pfSlots : &c.pfSlots;
     if (ar) { a.scratch = ar->scratch; a.counter = ar->counter; }
     if (hcLevel) {
         // per wave: bins, links, and 6 bytes + 1 bit per block position (chain, packed chain words, hit bits) — 10 bytes at levels
@@ -286,11 +360,15 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
             const bool withBest = needBest || c.hcHasBest;
             const size_t capA = cap > c.hcMaxBlock ? cap : c.hcMaxBlock;                 // (a re-allocation never shrinks what the slots take)
             const size_t slotBytes = LZ_HC_SLOT_BYTES(capA) - (withBest ? 0u : 4u * capA);
-            if (c.hcSlots) { LZ_HIP(hipDeviceSynchronize()); LZ_HIP(hipFree(c.hcSlots)); c.hcSlots = nullptr; c.hcNSlots = 0; }
+            if (c.hcSlots) { LZ_HIP(hipDeviceSynchronize()); dev_free(c, c.hcSlots, c.hcNSlots * c.hcSlotBytes); c.hcSlots = nullptr; c.hcNSlots = 0; }
             size_t freeB = 0, totalB = 0;
             LZ_HIP(hipMemGetInfo(&freeB, &totalB));
             size_t budget = freeB / 2u;
             if (budget > ((size_t)128 << 30)) budget = (size_t)128 << 30;
+            if (g_budget) {                                      // LizardGPU_setMemoryBudget: what other levels left behind goes first
+                if (budget_room(c) < (size_t)c.cus * LZ_MAX_WAVES * slotBytes) free_tables_except(c, 3);
+                if (budget > budget_room(c)) budget = budget_room(c);
+            }
             // LIZARDGPU_HC_WORKAREA_MB caps the reservation (a caller that shares the device with other allocations); fewer work
             // areas than resident waves only means fewer hashChain blocks in flight (the waves without one leave)
             if (const char* e = getenv("LIZARDGPU_HC_WORKAREA_MB")) {
@@ -300,7 +378,7 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
             size_t nSlots = budget / slotBytes;
             if (nSlots > (size_t)c.cus * LZ_MAX_WAVES) nSlots = (size_t)c.cus * LZ_MAX_WAVES;
             if (nSlots == 0) { snprintf(t_err, sizeof t_err, "level %d: no room for a hashChain work area of %zu bytes", lv, slotBytes); return -LIZARDGPU_ERR_NOMEM; }
-            LZ_HIP(hipMalloc((void**)&c.hcSlots, nSlots * slotBytes));
+            { const int rc_ = dev_alloc(c, (void**)&c.hcSlots, nSlots * slotBytes, "hashChain work areas"); if (rc_) return rc_; }
             c.hcMaxBlock = capA; c.hcNSlots = nSlots; c.hcHasBest = withBest; c.hcSlotBytes = slotBytes;
             if (getenv("LIZARDGPU_VERBOSE"))
                 fprintf(stderr, "liblizard_amd: device %d: hashChain levels reserve %zu work areas of %zu bytes (%.1f GiB of %.1f GiB free; LIZARDGPU_HC_WORKAREA_MB caps it)\n",
@@ -308,11 +386,11 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
         }
         a.tables = c.hcSlots; a.tableStride = c.hcSlotBytes; a.tableSlots = (u32)c.hcNSlots;
     } else if (lv == 11 || lv == 31 || lv == 22 || lv == 42) {
-        if (!*tablesAt) LZ_HIP(hipMalloc((void**)tablesAt, (size_t)c.cus * LZ_MAX_WAVES * LZ_TABWIDE_BYTES(18)));
-        a.tables = *tablesAt; a.tableStride = LZ_TABWIDE_BYTES(18);
+        if (!*tablesAt && (rc = alloc_table_slots(c, tablesAt, tablesSlotsAt, LZ_TABWIDE_BYTES(18), 1, !ar, "tables of levels 11/31/22/42"))) return rc;
+        a.tables = *tablesAt; a.tableStride = LZ_TABWIDE_BYTES(18); a.tableSlots = (u32)*tablesSlotsAt;
     } else if (!((lv == 10 || lv == 30) && LZ_FAST12_SPLIT)) {             // (the producer / consumer form keeps every table in LDS)
-        if (!*pfTablesAt) LZ_HIP(hipMalloc((void**)pfTablesAt, (size_t)c.cus * LZ_MAX_WAVES * LZ_PF_SLOT_BYTES));
-        a.tables = *pfTablesAt; a.tableStride = LZ_PF_SLOT_BYTES;
+        if (!*pfTablesAt && (rc = alloc_table_slots(c, pfTablesAt, pfSlotsAt, LZ_PF_SLOT_BYTES, 2, !ar, "tables of levels 21/41"))) return rc;
+        a.tables = *pfTablesAt; a.tableStride = LZ_PF_SLOT_BYTES; a.tableSlots = (u32)*pfSlotsAt;
     }
     u32 grid = (u32)((nBlocks + perGroup - 1) / perGroup);
     if (grid > (u32)c.cus) grid = (u32)c.cus;
@@ -441,7 +519,7 @@ int LizardGPU_residentWaves(void)
     return rc ? rc : g.c->cus * (LZ_FAST12_SPLIT ? LZ_SPLIT_PROD : LZ_WAVES_FAST);      // level-10 residency: blocks in flight = waves with a hash table (13 per CU, all in LDS)
 }
 
-void LizardGPU_shutdown(void)
+static void release_all_contexts(size_t newBudget, bool setBudget)
 {
     int saved = -1;
     if (hipGetDevice(&saved) != hipSuccess) saved = -1;
@@ -450,11 +528,74 @@ void LizardGPU_shutdown(void)
         lzk_combiner_quiesce(&c);                       // no batch of one-block callers is between its launch and its copy-out
         pthread_mutex_lock(&c.mu);
         ctx_release(c);
+        if (setBudget && d == 0) g_budget = newBudget;  // (under a context lock: launches read it under theirs)
         pthread_mutex_unlock(&c.mu);
         lzk_combiner_resume(&c);
     }
-    lz_shard_shutdown();
     if (saved >= 0) (void)hipSetDevice(saved);
+}
+
+void LizardGPU_shutdown(void)
+{
+    release_all_contexts(0, false);
+    lz_shard_shutdown();
+}
+
+int LizardGPU_setMemoryBudget(size_t bytes)
+{
+    t_err[0] = 0;
+    if (bytes) {
+        int dev = selected_device(), count = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || dev >= count || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            (void)hipGetLastError();
+            snprintf(t_err, sizeof t_err, "no HIP device visible");
+            return -LIZARDGPU_ERR_NO_DEVICE;
+        }
+        const size_t floor_ = (size_t)prop.multiProcessorCount * kScratchBytes + ((size_t)256 << 20);
+        if (bytes < floor_) {
+            snprintf(t_err, sizeof t_err, "LizardGPU_setMemoryBudget(%zu): below the minimum of %zu bytes (one scratch arena of %zu bytes + 256 MiB)", bytes, floor_, floor_ - ((size_t)256 << 20));
+            return -LIZARDGPU_ERR_ARG;
+        }
+    }
+    release_all_contexts(bytes, true);                  // what the contexts hold goes back; the next call allocates under the new budget
+    return 0;
+}
+
+size_t LizardGPU_memoryBudget(void) { return g_budget; }
+
+size_t LizardGPU_memoryInUse(void)
+{
+    Guard g;
+    return g.rc ? 0 : g.c->devBytes;
+}
+
+// Give back what is idle on the selected device: extra arenas, per-wave tables, hashChain work areas, the staging buffers of the
+// host-buffer entries and of the one-block combiner.  The context's own scratch arena stays.  Waits for the device to be idle.
+int LizardGPU_trim(void)
+{
+    LzCtx* const cpeek = lzk_ctx_peek();
+    if (!cpeek) return -LIZARDGPU_ERR_NO_DEVICE;
+    lzk_combiner_quiesce(cpeek);
+    int rc = 0;
+    {
+        Guard g;
+        rc = g.rc;
+        if (!rc && g.c->ready) {
+            Ctx& c = *g.c;
+            free_tables_except(c, 0);
+            for (Stage& s : c.stage) {
+                dev_free(c, s.d_in, s.d_in_cap); dev_free(c, s.d_slots, s.d_slots_cap); dev_free(c, s.d_packed, s.d_packed_cap);
+                s.d_in = s.d_slots = s.d_packed = nullptr; s.d_in_cap = s.d_slots_cap = s.d_packed_cap = 0;
+                if (s.h_in) (void)hipHostFree(s.h_in);
+                if (s.h_out) (void)hipHostFree(s.h_out);
+                s.h_in = s.h_out = nullptr; s.h_in_cap = s.h_out_cap = 0;
+            }
+            if (g.c == cpeek) lzk_combiner_free(&c);
+        }
+    }
+    lzk_combiner_resume(cpeek);
+    return rc;
 }
 
 int LizardGPU_compressBlocks_device(const void* d_src, size_t nBlocks, size_t blockSize, size_t lastBlockSize,
@@ -486,6 +627,15 @@ int   lzk_launch(LzCtx* c, const void* d_src, size_t nBlocks, size_t blockSize, 
 {
     return launch(*c, d_src, nBlocks, blockSize, lastBlockSize, d_dst, dstStride, d_sizes, level, stream, k0, k1, d_srcSizes, (const u64*)d_srcOffsets);
 }
+int    lzk_dev_alloc(LzCtx* c, void** p, size_t bytes)
+{
+    // staging of a host-buffer call (context locked by the caller): under a budget, the tables and work areas earlier launches left
+    // behind make room for it (this call's own launch gets as many table slots as still fit)
+    if (bytes > budget_room(*c)) free_tables_except(*c, 0);
+    return dev_alloc(*c, p, bytes, "staging buffer");
+}
+void   lzk_dev_free(LzCtx* c, void* p, size_t bytes) { dev_free(*c, p, bytes); }
+size_t lzk_budget(void) { return g_budget; }
 LzCtx* lzk_ctx_peek(void)
 {
     int count = 0;

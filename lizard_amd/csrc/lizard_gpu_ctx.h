@@ -53,6 +53,7 @@ typedef struct LzCombine {
 #define LZ_ARENAS_MAX 4
 typedef struct LzArena {
     uint8_t* scratch; uint32_t* counter; uint8_t* tables; uint8_t* pfTables;
+    size_t tablesSlots, pfSlots;  /* table slots behind tables / pfTables (fewer than resident waves under a memory budget) */
     hipEvent_t ev0, ev1;        /* around its last launch */
     hipStream_t lastStream;
     int timed;                  /* ev1 was recorded */
@@ -67,6 +68,10 @@ typedef struct LzCtx {
     uint8_t* hcSlots;           /* hashChain levels, allocated on first use / when a larger block size arrives */
     size_t   hcMaxBlock, hcNSlots, hcSlotBytes;
     int      hcHasBest;         /* the slots end with the first-search table of levels 16/17/37/38 */
+    size_t   tablesSlots, pfSlots;   /* table slots behind tables / pfTables (fewer than resident waves under a memory budget) */
+    size_t   devBytes;          /* device memory this context holds in its large buffers (arenas, tables, work areas, staging): what
+                                 * LizardGPU_setMemoryBudget bounds and LizardGPU_memoryInUse reports */
+    int      idleLaunches;      /* launches on the context's own arena since an extra arena was last used (they are released after 64) */
     uint8_t* scratch;
     uint32_t* counter;
     hipEvent_t ev0, ev1;
@@ -95,6 +100,10 @@ void  lzk_guard_release(LzGuard* g);
 char* lzk_err(void);                                        /* the calling thread's error text, LZK_ERR_BYTES bytes */
 #define LZK_ERR_BYTES 256
 int   lzk_ctx_init(LzCtx* c);
+/* device memory of the context's large buffers: counted against the memory budget (-LIZARDGPU_ERR_NOMEM when it does not fit) */
+int   lzk_dev_alloc(LzCtx* c, void** p, size_t bytes);
+void  lzk_dev_free(LzCtx* c, void* p, size_t bytes);
+size_t lzk_budget(void);                                    /* 0 = none */
 int   lzk_clamp_level(int level);
 /* the block kernels over nBlocks blocks resident at d_src (launcher of LizardGPU_compressBlocks_device); k0 / k1 (may be NULL)
  * are recorded around the kernel; d_srcSizes / d_srcOffsets (may be NULL): a ragged batch, block b = d_srcSizes[b] bytes at d_src + d_srcOffsets[b] */

@@ -12,6 +12,9 @@ int lzgpu_compress_one(const void* src, int srcSize, void* dst, int maxDstSize, 
  * built on the device, one D2H per chunk.  0 or -LIZARDGPU_ERR_*. */
 int lzgpu_frame_records(const void* src, size_t nBlocks, size_t blockSize, size_t lastBlockSize, void* dst, size_t dstCapacity,
                         size_t* written, int level);
+/* a call degraded (returned 0 / stored its blocks raw) because the GPU path could not do it: counted, and reported on stderr for
+ * the 1st, 2nd, 4th, 8th ... occurrence (lizard_host.c) */
+void lzgpu_note_degraded(const char* what, int level);
 #ifdef __cplusplus
 }
 #endif

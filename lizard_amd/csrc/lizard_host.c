@@ -26,14 +26,20 @@ static int verify_level(int level)                               /* reference li
     return level;
 }
 
-static void complain(const char* what, int level)
+/* A call that could not compress (level without a kernel, no device, HIP failure) returns 0 — "compression failed", as the
+ * reference's contract says (lib/lizard_compress.h:113) — and the frame layer then stores its blocks raw.  That is silent towards
+ * the caller, so it is loud on stderr: the 1st, 2nd, 4th, 8th ... such call of the process prints a line with the reason (a
+ * long-running service keeps hearing about it without being flooded), and LizardGPU_degradedCalls() counts every one of them. */
+static unsigned long long g_degraded;
+void lzgpu_note_degraded(const char* what, int level)
 {
-    static int warned = 0;
-    if (!__atomic_exchange_n(&warned, 1, __ATOMIC_RELAXED)) {
-        fprintf(stderr, "liblizard_amd: %s (level %d): %s — returning 0 (no CPU fallback in this library)\n",
-                what, level, LizardGPU_lastError());
-    }
+    const unsigned long long n = __atomic_add_fetch(&g_degraded, 1ull, __ATOMIC_RELAXED);
+    if ((n & (n - 1ull)) == 0)
+        fprintf(stderr, "liblizard_amd: %s (level %d): %s — no CPU fallback in this library [occurrence %llu in this process, see LizardGPU_degradedCalls()]\n",
+                what, level, LizardGPU_lastError()[0] ? LizardGPU_lastError() : "level not implemented on the GPU path", n);
 }
+unsigned long long LizardGPU_degradedCalls(void) { return __atomic_load_n(&g_degraded, __ATOMIC_RELAXED); }
+static void complain(const char* what, int level) { lzgpu_note_degraded(what, level); }
 
 int Lizard_versionNumber(void) { return LIZARD_VERSION_NUMBER; }
 int Lizard_compressBound(int isize) { return LIZARD_COMPRESSBOUND(isize); }
@@ -48,9 +54,9 @@ int Lizard_compress_extState(void* state, const char* src, char* dst, int srcSiz
 {
     int level = verify_level(compressionLevel), r;
     if (((size_t)state & (sizeof(void*) - 1)) != 0) return 0;   /* reference lib/lizard_compress.c:586 */
-    if (!LizardGPU_levelSupported(level)) { complain("level not implemented on the GPU path", level); return 0; }
+    if (!LizardGPU_levelSupported(level)) { complain("returning 0: level not implemented on the GPU path", level); return 0; }
     r = lzgpu_compress_one(src, srcSize, dst, maxDstSize, level);
-    if (r < 0) { complain("GPU compression failed", level); return 0; }
+    if (r < 0) { complain("returning 0: GPU compression failed", level); return 0; }
     return r;
 }
 

@@ -28,11 +28,12 @@
         }                                                                                              \
     } while (0)
 
-static int ensure_dev(void** p, size_t* cap, size_t need)
+static int ensure_dev(LzCtx* c, void** p, size_t* cap, size_t need)
 {
+    int rc;
     if (*cap >= need) return 0;
-    if (*p) { LZ_HIP(hipFree(*p)); *p = NULL; *cap = 0; }
-    LZ_HIP(hipMalloc(p, need));
+    if (*p) { lzk_dev_free(c, *p, *cap); *p = NULL; *cap = 0; }
+    if ((rc = lzk_dev_alloc(c, p, need))) return rc;        /* counted against the memory budget */
     *cap = need;
     return 0;
 }
@@ -111,6 +112,14 @@ static size_t chunk_bytes(void)
         if (mb < 1 || mb > 65536) mb = 256;                  /* measured on a 4 GiB job: 256 MiB 37 GB/s, 512 MiB 26, 1 GiB 23 (fill and drain of the pipeline) */
         g_chunk_bytes = mb << 20;
     }
+    {   /* under a memory budget (LizardGPU_setMemoryBudget) the three stages' device buffers — about 3 x 3 chunks — take a sixth of it */
+        const size_t b = lzk_budget();
+        if (b) {
+            size_t c = (b / 64) & ~(((size_t)1 << 20) - 1);
+            if (c < ((size_t)8 << 20)) c = (size_t)8 << 20;
+            if (c < g_chunk_bytes) return c;
+        }
+    }
     return g_chunk_bytes;
 }
 
@@ -133,9 +142,9 @@ static int stage_issue(LzCtx* c, LzStage* s, const HostJob* j, ChunkState* ch, i
     const uint8_t* from;
     int rc;
     ch->inBytes = (ch->nb - 1) * j->blockSize + last;
-    if ((rc = ensure_dev((void**)&s->d_in, &s->d_in_cap, ch->inBytes + 64))) return rc;
-    if ((rc = ensure_dev((void**)&s->d_slots, &s->d_slots_cap, ch->nb * slot))) return rc;
-    if ((rc = ensure_dev((void**)&s->d_packed, &s->d_packed_cap, packedCap))) return rc;
+    if ((rc = ensure_dev(c, (void**)&s->d_in, &s->d_in_cap, ch->inBytes + 64))) return rc;
+    if ((rc = ensure_dev(c, (void**)&s->d_slots, &s->d_slots_cap, ch->nb * slot))) return rc;
+    if ((rc = ensure_dev(c, (void**)&s->d_packed, &s->d_packed_cap, packedCap))) return rc;
     if ((rc = ensure_pinned((void**)&s->h_out, &s->h_out_cap, packedCap + 64))) return rc;    /* worst case once: a buffer that follows the chunks' sizes is re-pinned again and again */
     if ((rc = ensure_meta(s, ch->nb + 1))) return rc;
     from = j->src + ch->first * j->blockSize;
@@ -456,8 +465,8 @@ static int batch_buffers(LzCtx* c, int n, size_t inBytes, size_t maxSize)
     int rc = lzk_ctx_init(c);
     if (rc) return rc;
     if (!s->stream) LZ_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-    if ((rc = ensure_dev((void**)&s->d_in, &s->d_in_cap, inBytes + 64))) return rc;
-    if ((rc = ensure_dev((void**)&s->d_slots, &s->d_slots_cap, (size_t)n * slot))) return rc;
+    if ((rc = ensure_dev(c, (void**)&s->d_in, &s->d_in_cap, inBytes + 64))) return rc;
+    if ((rc = ensure_dev(c, (void**)&s->d_slots, &s->d_slots_cap, (size_t)n * slot))) return rc;
     if ((rc = ensure_pinned((void**)&s->h_in, &s->h_in_cap, inBytes + 64))) return rc;
     if ((rc = ensure_pinned((void**)&s->h_out, &s->h_out_cap, (size_t)n * slot))) return rc;
     if (k->raggedCap < (size_t)n + 1) {
@@ -494,9 +503,9 @@ void lzk_combiner_free(LzCtx* c)                /* context locked, no batch unde
     if (s->h_offsets) (void)hipHostFree(s->h_offsets);
     if (k->h_srcSizes) (void)hipHostFree(k->h_srcSizes);
     if (k->h_srcOffsets) (void)hipHostFree(k->h_srcOffsets);
-    if (s->d_in) (void)hipFree(s->d_in);
-    if (s->d_slots) (void)hipFree(s->d_slots);
-    if (s->d_packed) (void)hipFree(s->d_packed);
+    if (s->d_in) lzk_dev_free(c, s->d_in, s->d_in_cap);
+    if (s->d_slots) lzk_dev_free(c, s->d_slots, s->d_slots_cap);
+    if (s->d_packed) lzk_dev_free(c, s->d_packed, s->d_packed_cap);
     if (s->d_sizes) (void)hipFree(s->d_sizes);
     if (s->d_offsets) (void)hipFree(s->d_offsets);
     if (k->d_srcSizes) (void)hipFree(k->d_srcSizes);
@@ -699,9 +708,9 @@ static int decompress_host_locked(LzCtx* c, const void* src, const uint64_t* off
     }
     if (dstStride > (size_t)-1 / nBlocks) { snprintf(lzk_err(), LZK_ERR_BYTES, "bad argument (nBlocks * dstStride overflows)"); return -LIZARDGPU_ERR_ARG; }
     inBytes = (size_t)(offsets[nBlocks] - offsets[0]);
-    if ((rc = ensure_dev((void**)&s->d_in, &s->d_in_cap, inBytes + 64))) return rc;
-    if ((rc = ensure_dev((void**)&s->d_slots, &s->d_slots_cap, nBlocks * dstStride))) return rc;
-    if ((rc = ensure_dev((void**)&s->d_packed, &s->d_packed_cap, (nBlocks + 1) * sizeof(uint64_t) + nBlocks * sizeof(uint32_t)))) return rc;   /* offsets + sizes ride here */
+    if ((rc = ensure_dev(c, (void**)&s->d_in, &s->d_in_cap, inBytes + 64))) return rc;
+    if ((rc = ensure_dev(c, (void**)&s->d_slots, &s->d_slots_cap, nBlocks * dstStride))) return rc;
+    if ((rc = ensure_dev(c, (void**)&s->d_packed, &s->d_packed_cap, (nBlocks + 1) * sizeof(uint64_t) + nBlocks * sizeof(uint32_t)))) return rc;   /* offsets + sizes ride here */
     d_off = (uint64_t*)s->d_packed;
     d_out = (uint32_t*)(d_off + nBlocks + 1);
     rel = (uint64_t*)malloc((nBlocks + 1) * sizeof(uint64_t));

@@ -39,7 +39,7 @@ for n in sorted(rows):
     pr = r.get("per_rank") or []
     tr = (r.get("config") or {}).get("size_gather_transport") or {}
     print(f"{n:>2} {r['value']:>12.0f} {r['value'] / n:>13.0f} {r['value'] / (n * base):>10.3f} "
-          f"{max([p['kernel_ms'] for p in pr], default=float('nan')):>14.3f} {max([p['gather_us'] for p in pr], default=float('nan')):>14.1f}  "
+          f"{max([p['kernel_ms'] for p in pr], default=(r.get('roofline') or {}).get('avg_kernel_ms', float('nan'))):>14.3f} {max([p['gather_us'] for p in pr], default=0.0):>14.1f}  "
           f"{tr.get('rccl_ranks_seen', '-')} / {tr.get('rccl_version', '-')}")
     for c in r.get("configs", []):
         print(f"   {c['workload'][:60]:<60} {c['value']:>12.0f} MB/s")
