@@ -84,8 +84,12 @@ int Lizard_compress_continue(Lizard_stream_t* streamPtr, const char* src, char* 
 /* ======================= Part 1b: reference block decompression (lib/lizard_decompress.h) =======================
  * One block per call, on the calling thread (lizard_amd/csrc/lizard_decode_host.c): the decoder is not the path this library
  * accelerates, and one block is ~0.1 ms of host work against ~1 ms as a single wavefront.  Many independent blocks:
- * LizardGPU_decompressBlocks_host / _device below.  Same results as the reference for every valid block; malformed input is
- * refused (negative result) without reading outside source[0..compressedSize) or writing outside dest[0..maxDecompressedSize). */
+ * LizardGPU_decompressBlocks_host / _device below.  Same results as the reference for every VALID block (every block a Lizard
+ * compressor produces: offsets >= 8).  Malformed input is refused (negative result) without reading outside
+ * source[0..compressedSize) or writing outside dest[0..maxDecompressedSize) — and that is where the identity ends: an offset of
+ * 0 is refused here, offsets 1..7 copy with true LZ overlap semantics (the reference's 8- and 16-byte wild copies produce a
+ * different byte pattern for them), and a literal run that overruns the literals stream is refused (the reference has no such
+ * test).  tests/decode_fuzz.c runs the decoder under ASan / UBSan on damaged blocks. */
 typedef struct Lizard_streamDecode_s Lizard_streamDecode_t;   /* 4 words, valid when zeroed (reference lib/lizard_common.h:195-200) */
 /* reference lib/lizard_decompress.h:64 / lib/lizard_decompress.c:267 */
 int Lizard_decompress_safe(const char* source, char* dest, int compressedSize, int maxDecompressedSize);

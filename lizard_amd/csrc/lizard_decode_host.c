@@ -411,7 +411,7 @@ static long decode_lz4(const Env* e, Streams* s, u8* const dest, size_t cap)
     {   /* last literals: the rest of the stream (:145-151) */
         const long rest = (long)(iend - lp);
         if (rest < 0 || rest > (long)(oend - op)) return -1;
-        memcpy(op, lp, (size_t)rest);
+        if (rest) memcpy(op, lp, (size_t)rest);                               /* (dest may be NULL with a capacity of 0) */
         op += rest;
     }
     return (long)(op - dest);
@@ -470,7 +470,7 @@ static long decode_lizv1(const Env* e, Streams* s, u8* const dest, size_t cap)
     {   /* last literals (:204-211) */
         const long rest = (long)(iend - lp);
         if (rest < 0 || rest > (long)(oend - op)) return -1;
-        memcpy(op, lp, (size_t)rest);
+        if (rest) memcpy(op, lp, (size_t)rest);                               /* (dest may be NULL with a capacity of 0) */
         op += rest;
     }
     return (long)(op - dest);
@@ -525,7 +525,7 @@ static int decode_block(const u8* src, int srcSize, u8* dst, int dstCap, int par
             if (iend - ip < 3) goto done;
             n = le24(ip); ip += 3;
             if (n > (size_t)(iend - ip) || n > (size_t)(oend - op)) goto done;
-            memcpy(op, ip, n);
+            if (n) memcpy(op, ip, n);
             op += n; ip += n;
             if (partial && op >= dst + e.target) break;
             continue;

@@ -22,6 +22,7 @@ int lzgpu_frame_records(const void* src, size_t nBlocks, size_t blockSize, size_
 { (void)src; (void)nBlocks; (void)blockSize; (void)lastBlockSize; (void)dst; (void)dstCapacity; (void)written; (void)level; return -1; }
 int LizardGPU_levelSupported(int level) { (void)level; return 0; }
 const char* LizardGPU_lastError(void) { return "decode_fuzz: no device"; }
+void lzgpu_note_degraded(const char* what, int level) { (void)what; (void)level; }
 
 static unsigned g_rng;
 static unsigned rnd(void) { g_rng = g_rng * 1664525u + 1013904223u; return g_rng >> 8; }
