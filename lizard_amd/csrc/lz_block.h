@@ -218,14 +218,30 @@ LZ_DEV void lz_seq_flush(LzStreams& st)
     if (lz_lane() < pending) lz_stq_s(&st.seq[st.nseq - pending + lz_lane()], st.ring[lz_lane()]);
     lz_lds_sync();
 }
+// LEAN (the producers of lz_split.h): only the list entry; the stream sizes the container's rules need (nflags = one token per
+// sequence, nlit = the records' bytes) are summed up by the CONSUMER, 64 sequences per step (lz_seq_sizes), instead of ~15 scalar
+// instructions per sequence on the producer's serial chain.
+template <bool LEAN = false>
 LZ_DEV void lz_seq_push(LzStreams& st, u32 L, u32 ml, u32 off)
 {
     const u32 mlc = ml - 4u;
     if (lz_lane() == 0) st.ring[st.nseq & (LZ_SEQ_RING - 1u)] = (u64)L | ((u64)mlc << 18) | ((u64)off << 36);
     lz_converge();
-    st.nseq += 1u; st.nflags += 1u;
-    st.nlit += lz_lz4_record_bytes(L, mlc);
+    st.nseq += 1u;
+    if constexpr (!LEAN) { st.nflags += 1u; st.nlit += lz_lz4_record_bytes(L, mlc); }
     if ((st.nseq & (LZ_SEQ_RING - 1u)) == 0) lz_seq_flush(st);
+}
+// nflags / nlit of a finished fastLZ4 sequence list (what lz_seq_push keeps up to date when it is not LEAN): wave-parallel
+LZ_DEV void lz_seq_sizes(LzStreams& st)
+{
+    u32 sum = 0;
+    for (u32 base = 0; base < st.nseq; base += 64u) {
+        const u32 i = base + lz_lane();
+        const u64 q = lz_ldq_s(&st.seq[i < st.nseq ? i : st.nseq - 1u]);
+        sum += i < st.nseq ? lz_lz4_record_bytes((u32)q & 0x3FFFFu, (u32)(q >> 18) & 0x3FFFFu) : 0u;
+    }
+    st.nflags = st.nseq;
+    st.nlit = st.lastLits + lz_wave_reduce_add(sum);
 }
 
 // Literal runs of one encode step (64 sequences, one per lane): run of lane j = L bytes from src + mySrc to
@@ -496,7 +512,10 @@ LZ_DEV u32 lz_back_from(u32 cb, u32 P, u32 M, u32 anchor)
 #ifndef LZ_FAST_CHAIN
 #define LZ_FAST_CHAIN 1
 #endif
-template <int HASHLOG, class TAB>
+// (Measured in round 5 and not kept, profiles/r05j_m_*: 32 bytes forward in the candidate batch instead of 24 — two more loads per
+//  candidate lane — is 5.3 % SLOWER at level 10 (191.9 vs 202.7 GB/s) although it halves the matches that need a second trip; 16
+//  bytes forward is the same as 24 within 0.3 %.)
+template <int HASHLOG, class TAB, bool LEAN = false>
 LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStreams& st)
 {
     constexpr bool kChain = (TAB::kXchg || TAB::kTagDedup) && LZ_FAST_CHAIN;   // several sequences out of one round (see below)
@@ -655,7 +674,7 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
                         // (global tables: nothing was stored yet, the entry came from that lane's registers)
                         const bool stale = TAB::kXchg ? (age <= lane && ((dead2 >> (lane - age)) & 1ull)) : (jPrev < 64u && ((dead2 >> jPrev) & 1ull));
                         if (lz_ballot(stale) & readers) break;
-                        lz_seq_push(st, Pw - bk - anchor, fw + bk, Pw - Mw);      // fast.h:138
+                        lz_seq_push<LEAN>(st, Pw - bk - anchor, fw + bk, Pw - Mw);      // fast.h:138
                         anchor = ipn;
                         deadMask = dead2; commit |= readers; w = w2;
                     }
@@ -718,7 +737,7 @@ LZ_DEV void lz_parse_fast(const u8* src, u32 S, u32 E, const TAB& table, LzStrea
         if constexpr (kNarrow) { W = kW0; validNext = validNext && lane < kW0; }
         if (ip > mflimit) validNext = false;                             // (fast.h:143: there is no next run; any readable address)
         nextBytes = lz_ld64(src + (validNext ? pNext : S));
-        lz_seq_push(st, P - anchor, ml, P - M);                          // fast.h:138 (encoded later, in parallel)
+        lz_seq_push<LEAN>(st, P - anchor, ml, P - M);                    // fast.h:138 (encoded later, in parallel)
         anchor = ip;
         if (ip > mflimit) goto tail;                                     // fast.h:143
     }

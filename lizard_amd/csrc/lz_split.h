@@ -18,6 +18,9 @@
 // Test infrastructure runs this file on the CPU with several emulated waves on OS threads (tests/emul, emul_compress_split).
 #pragma once
 #include "lz_block.h"
+#ifndef LZ_SPLIT_LEAN
+#define LZ_SPLIT_LEAN 1                                      // the consumers sum up the stream sizes (lz_seq_sizes), not the producers
+#endif
 
 // Per kernel (LzSplitArgs): nBufs = sequence buffers per producer, qn = mailbox words per consumer (a power of two >= nProd x nBufs)
 #define LZ_SPLIT_HDR      64u                                // job header bytes in front of a buffer's sequence list
@@ -113,7 +116,7 @@ LZ_DEV void lz_split_producer(const LzSplitArgs& a, const LzSplitShared& sh, u32
 #if LZ_FAST_128
             lz_parse_fast128<HASHLOG>(src, pos, pos + part, tab, st);
 #else
-            lz_parse_fast<HASHLOG>(src, pos, pos + part, tab, st);
+            lz_parse_fast<HASHLOG, LzTab, LZ_SPLIT_LEAN != 0>(src, pos, pos + part, tab, st);
 #endif
             // the job header
             {
@@ -186,6 +189,9 @@ LZ_DEV void lz_split_consumer(const LzSplitArgs& a, const LzSplitShared& sh, u32
         u32 op;
         if (flags & LZJ_FIRST) { if (lane == 0) dst[0] = (u8)a.level; lz_converge(); op = 1u; }
         else op = lz_uniform(lz_ld_shared_u32(opSlot));
+#if LZ_SPLIT_LEAN
+        lz_seq_sizes(st);                                                        // the stream sizes the producer did not keep (lz_seq_push<LEAN>)
+#endif
         if (E > S) op += lz_write_subblock_seq<HUF, false>(src, S, E, dst + op, st, pool);
         lz_wave_sync();                                                          // my reads of the list and my staging traffic are done
         if (flags & LZJ_LAST) { if (lane == 0) a.sizes[b] = op; }
