@@ -38,6 +38,12 @@ every block of its own shard and `blocks_checked` is the sum over ranks (== n_gp
 installs a transport of the library's size exchange (LizardGPU_setCollectives) that bounces through host memory: the same bench
 code path, the same library entry points, no RCCL — `config.size_gather` names the transport; such a line is a functional
 check of the N > 1 path, not a scaling measurement (the ranks share a device).
+`config.size_gather_transport` (N > 1) is what the transport itself reports (LizardGPU_commInfo): RCCL or an installed table, the
+ranks the communicator was made for, the ranks and rank ncclCommCount / ncclCommUserRank report, ncclGetVersion — an RCCL line whose
+communicator does not report --gpus ranks is REFUSED, not printed.  `config.scaling_note`: weak scaling, blocks_per_gpu blocks per GPU
+at every N (scripts/scale.sh runs N = 1, 2, 4, 8 and prints the efficiencies).
+"config1.reference_program": BASELINE configs[0] literally — the reference's own program (oracle/_ref/lizard_cli_ref, `lizard -bL -eL
+-B262144 -i3`) on the same 64 MiB buffer, levels 10 / 21 / 30, with the host CPU model.
 "one_block_callers": aggregate MB/s of 1..64 host threads calling the reference's one-block Lizard_compress at once (the
 combiner, tests/gpu_threads.c).  "concurrent_streams": 4 streams x 20 launches of 64 blocks queued without host synchronisation
 (a launch smaller than the machine gets an arena of its own and runs beside the others).  "frames": the reference's own frame entry point LizardF_compressFrame on a 4 GiB host buffer.
