@@ -83,6 +83,10 @@ struct LzV256 {
         r0 = lz_writelane(r0, x, c == 0 ? l : 64u); r1 = lz_writelane(r1, x, c == 1 ? l : 64u);
         r2 = lz_writelane(r2, x, c == 2 ? l : 64u); r3 = lz_writelane(r3, x, c == 3 ? l : 64u);
     }
+    // the register that holds entries 64c .. 64c+63 (c wave-uniform), and putting one back: what a cursor that moves through the
+    // table in one direction works on (lz_put_stream_huf's two-queue merge)
+    LZ_DEVM u32  reg(u32 c) const { return c == 0 ? r0 : c == 1 ? r1 : c == 2 ? r2 : r3; }
+    LZ_DEVM void putReg(u32 c, u32 v) { r0 = c == 0 ? v : r0; r1 = c == 1 ? v : r1; r2 = c == 2 ? v : r2; r3 = c == 3 ? v : r3; }
 };
 
 // LSB-first bit writer whose output is a register table of 64 dwords (the weight header is < 256 bytes)
@@ -503,18 +507,36 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
                 nodeC.set(0, c); parL.set((u32)lowS, 0); parL.set((u32)lowS - 1u, 0);
                 nodeNb = 1; lowS -= 2;
             }
-            u32 curS = lowS >= 0 ? leaf.get((u32)lowS) >> 8 : BAR;
-            u32 curN = nodeC.get(0);
+            // The queues move one way — leaves from rank lowS downwards, nodes from lowN upwards, new nodes at nodeNb upwards — so the
+            // 64 entries around each cursor ride in ONE register: an access is a v_readlane / a compare-and-select on that register
+            // instead of four of each with a scalar selection behind them (LzV256::get / ::set); a cursor that crosses into the next
+            // 64 entries writes its register back and takes the next (three times per table at most).
+            u32 chS = lowS >= 0 ? (u32)lowS >> 6 : 0u, chR = 0, chW = 0;         // chunks of the leaf cursor, the node read cursor, the node write cursor
+            u32 leafReg = leaf.reg(chS), parLReg = parL.reg(chS);
+            u32 nodeW = nodeC.r0, nodeR = 0, parNReg = parN.r0;
+            u32 curS = lowS >= 0 ? lz_readlane(leafReg, (u32)lowS & 63u) >> 8 : BAR;
+            u32 curN = lz_readlane(nodeW, 0u);
             while (nodeNb <= kRoot) {                          // :353-369 (a leaf is taken only when strictly smaller)
                 u32 sum = 0;
                 for (u32 pick = 0; pick < 2u; pick++) {
-                    if (curS < curN) { sum += curS; parL.set((u32)lowS, nodeNb); lowS--; curS = lowS >= 0 ? leaf.get((u32)lowS) >> 8 : BAR; }
-                    else             { sum += curN; parN.set(lowN, nodeNb); lowN++; curN = lowN < nodeNb ? nodeC.get(lowN) : BIG; }
+                    if (curS < curN) {
+                        sum += curS; parLReg = lz_writelane(parLReg, nodeNb, (u32)lowS & 63u); lowS--;
+                        if (lowS >= 0) {
+                            if (((u32)lowS & 63u) == 63u) { parL.putReg(chS, parLReg); chS--; leafReg = leaf.reg(chS); parLReg = parL.reg(chS); }
+                            curS = lz_readlane(leafReg, (u32)lowS & 63u) >> 8;
+                        } else curS = BAR;
+                    } else {
+                        sum += curN; parNReg = lz_writelane(parNReg, nodeNb, lowN & 63u); lowN++;
+                        if ((lowN & 63u) == 0u) { parN.putReg(chR, parNReg); chR++; parNReg = parN.reg(chR); if (chR < chW) nodeR = nodeC.reg(chR); }
+                        curN = lowN < nodeNb ? lz_readlane(chR == chW ? nodeW : nodeR, lowN & 63u) : BIG;
+                    }
                 }
-                nodeC.set(nodeNb, sum);
+                nodeW = lz_writelane(nodeW, sum, nodeNb & 63u);
                 if (lowN == nodeNb) curN = sum;                // the new node is the head of the node queue
                 nodeNb++;
+                if ((nodeNb & 63u) == 0u) { nodeC.putReg(chW, nodeW); chW++; nodeW = 0; if (chR < chW) nodeR = nodeC.reg(chR); }
             }
+            parL.putReg(chS, parLReg); parN.putReg(chR, parNReg);
         }
         // depths (:371-376).  Node depths by pointer jumping in LDS: word k = distance << 8 | ancestor, the root points at itself;
         // after r rounds every node has jumped 2^r levels, eight rounds cover any tree of 256 leaves.  Then the leaves.
