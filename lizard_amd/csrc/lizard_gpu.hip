@@ -209,6 +209,7 @@ void free_extra_arenas(Ctx& c)                                   // (their launc
 {
     for (int i = 0; i < c.nExtra; i++) {
         LzArena& x = c.extra[i];
+        if (c.lastEv0 == x.ev0 || c.lastEv1 == x.ev1) { c.lastEv0 = c.ev0; c.lastEv1 = c.ev1; }      // (LizardGPU_lastKernelMs must not look at destroyed events)
         dev_free(c, x.scratch, (size_t)c.cus * kScratchBytes);
         if (x.counter) (void)hipFree(x.counter);
         dev_free(c, x.tables, x.tablesSlots * LZ_TABWIDE_BYTES(18));
