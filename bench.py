@@ -327,6 +327,14 @@ def verify_all_blocks(L, level, bs, nb, src, dst, sizes, stride, seed0, byte_blo
     return nb, n_bytes_checked, kind
 
 
+def launcher_argv(n, argv):
+    """The command `python bench.py --gpus N ...` turns itself into when no launcher started it: the driver's own N > 1 form."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -340,6 +348,8 @@ def main():
     ap.add_argument("--cpu-blocks", type=int, default=256)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / verification / end-to-end legs")
     ap.add_argument("--headline-only", action="store_true")
+    ap.add_argument("--strong", action="store_true", help="with --headline-only: also time the strong-scaling reading of BASELINE configs[4]")
+    ap.add_argument("--strong-blocks", type=int, default=4096, help="4 MiB blocks in the WHOLE job of the strong-scaling entry (divided by --gpus)")
     ap.add_argument("--transport", choices=("auto", "rccl", "host-bounce"), default="auto",
                     help="N > 1: the size exchange over RCCL (nccl backend), or bounced through host memory over gloo (ranks may share a device)")
     ap.add_argument("--cpu-all-seconds", type=float, default=3.0, help="all-cores CPU baseline: seconds per level (0 = skip)")
@@ -356,11 +366,18 @@ def main():
     import torch.distributed as dist
     from lizard_amd import _lib, api
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher — one rank per GPU under torch.distributed.run, same argv,
+        # a free port on 127.0.0.1 (the container's hostname may not resolve).  The ranks' single JSON line is this process's.
+        cmd = launcher_argv(args.gpus, sys.argv[1:])
+        sys.stdout.flush(); sys.stderr.flush()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.execv(cmd[0], cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus disagree")
     ndev = torch.cuda.device_count()
     transport = args.transport
     if transport == "auto":
@@ -454,14 +471,18 @@ def main():
         if info[1] != world:
             raise SystemExit(f"bench.py rank {rank}: --gpus {world} but the library's rank communicator was made for {info[1]} ranks")
 
+    # (level, block size, blocks PER GPU, scaling): "weak" = the same blocks per GPU at every N; "strong" = BASELINE configs[4] read
+    # literally — 4 096 x 4 MiB frame blocks in the whole job, 4 096 / N per GPU, the same 4 096 blocks at every N
     if args.level is not None:
-        plan = [(args.level, args.block_size, args.blocks or 16384)]
+        plan = [(args.level, args.block_size, args.blocks or 16384, "weak")]
     else:
-        plan = [(10, 262144, args.blocks or 65536)]
+        plan = [(10, 262144, args.blocks or 65536, "weak")]
         if not args.headline_only:
-            plan += [(21, 262144, 16384), (30, 262144, 16384), (10, 4 << 20, 6656)]
-    max_in = max(nb * bs for _, bs, nb in plan)
-    max_out = max(nb * ((api.Lizard_compressBound(bs) + 63) & ~63) for _, bs, nb in plan)
+            plan += [(21, 262144, 16384, "weak"), (30, 262144, 16384, "weak"), (10, 4 << 20, 6656, "weak")]
+        if not args.headline_only or args.strong:
+            plan += [(10, 4 << 20, max(1, args.strong_blocks // world), "strong")]
+    max_in = max(nb * bs for _, bs, nb, _ in plan)
+    max_out = max(nb * ((api.Lizard_compressBound(bs) + 63) & ~63) for _, bs, nb, _ in plan)
     src_all = torch.empty(max_in, dtype=torch.uint8, device=dev)
     dst_all = torch.empty(max_out, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev)
@@ -474,7 +495,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_config(level, bs, nb, with_cpu):
+    def run_config(level, bs, nb, with_cpu, scaling="weak"):
         if not L.LizardGPU_levelSupported(level):
             raise SystemExit(f"level {level} is not implemented on the GPU path")
         stride = (api.Lizard_compressBound(bs) + 63) & ~63
@@ -542,9 +563,8 @@ def main():
             alg_bytes = in_bytes + out_bytes                     # per launch on this GPU
             traffic, traffic_source = lookup_traffic(level, bs, nb)   # fabric bytes per launch from a committed counter pass of THESE kernels, else null
             res = {
-                "level": level, "block_size": bs, "blocks_per_gpu": nb,
-                "workload": f"level -{level}, {nb} x {bs} B independent blocks per GPU, datagen P50 "
-                            f"(block b = RDG_genBuffer(seed b)), inputs resident in HBM",
+                "level": level, "block_size": bs, "blocks_per_gpu": nb, "blocks_total": nb * world, "scaling": scaling,
+                "workload": f"L{level} {nb}x{bs}B blocks/GPU x {world} GPU ({scaling}), datagen P50 seed=block index, HBM-resident",
                 "value": round(tot_in * args.steps / elapsed / 1e6, 1), "unit": "MB/s",
                 "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                 "ratio": round(tot_in / tot_out, 4), "compressed_bytes": tot_out,
@@ -596,8 +616,8 @@ def main():
 
     with_cpu = not args.no_cpu
     results = []
-    for level, bs, nb in plan:
-        r, _ = run_config(level, bs, nb, with_cpu)
+    for level, bs, nb, scaling in plan:
+        r, _ = run_config(level, bs, nb, with_cpu, scaling)
         results.append(r)
 
     if rank == 0:
@@ -614,9 +634,10 @@ def main():
             "config": {"workload": head["workload"], "level": head["level"], "block_size": head["block_size"],
                        "blocks_per_gpu": head["blocks_per_gpu"], "resident_waves": int(L.LizardGPU_residentWaves()),
                        "size_gather": state["gather"], "size_gather_transport": comm_info,
-                       "scaling_note": ("weak scaling: every GPU compresses blocks_per_gpu blocks of its own (BASELINE configs[4], 4 MiB "
-                                        "frame blocks over 8 GPUs, runs as configs[] entry 'level 10 x 4 MiB' at 6 656 blocks PER GPU = two "
-                                        "per table-holding wave; a launch needs >= 3 328 blocks to fill one MI355X)")},
+                       "scaling_note": ("top level and configs[] with scaling=weak: every GPU compresses blocks_per_gpu blocks of its own. "
+                                        "BASELINE configs[4] (4 MiB frame blocks over 8 GPUs) is carried twice: weak, 6 656 blocks PER GPU "
+                                        "(two per table-holding wave; a launch needs >= 3 328 blocks to fill one MI355X), and strong, "
+                                        "4 096 blocks in the WHOLE job = 4 096 / N per GPU (SURVEY 8d read literally)")},
             "ratio": head["ratio"], "compressed_bytes": head["compressed_bytes"],
             "roofline": head["roofline"],
         }

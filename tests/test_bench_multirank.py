@@ -22,17 +22,24 @@ def _free_port():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,blocks", [(2, 1024), (3, 683)])
-def test_bench_two_and_three_ranks_on_one_device(world, blocks):
+@pytest.mark.parametrize("world,blocks,self_launch", [(2, 1024, True), (3, 683, False)])
+def test_bench_two_and_three_ranks_on_one_device(world, blocks, self_launch):
+    """self_launch: `python bench.py --gpus N` with no launcher on the command line and no WORLD_SIZE in the environment — the form
+    the driver uses for N = 1 — must start its own ranks; the other case is the driver's torchrun form."""
     import torch
     if torch.cuda.device_count() >= world:
         extra = ["--transport", "host-bounce"]               # (a box with enough devices: still exercise the bounce transport here)
     else:
         extra = []
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(util.ROOT, "bench.py"), "--gpus", str(world), "--headline-only",
-           "--blocks", str(blocks), "--steps", "2", "--warmup", "1", "--cpu-seconds", "1", "--cpu-all-seconds", "0"] + extra
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    tail = ["--gpus", str(world), "--headline-only", "--strong", "--strong-blocks", "96",
+            "--blocks", str(blocks), "--steps", "2", "--warmup", "1", "--cpu-seconds", "1", "--cpu-all-seconds", "0"] + extra
+    if self_launch:
+        cmd = [sys.executable, os.path.join(util.ROOT, "bench.py")] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(util.ROOT, "bench.py")] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MASTER_ADDR"] = "127.0.0.1"
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=util.ROOT)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -45,7 +52,12 @@ def test_bench_two_and_three_ranks_on_one_device(world, blocks):
     # and bench.py refuses to print a line when that is not --gpus)
     tr = out["config"]["size_gather_transport"]
     assert tr["transport"] == "LizardGPU_setCollectives table" and tr["ranks_requested"] == world and tr["rccl_ranks_seen"] == 0
-    assert "weak scaling" in out["config"]["scaling_note"]
+    assert "scaling=weak" in out["config"]["scaling_note"] and len(out["config"]["workload"]) <= 120
+    # BASELINE configs[4] read literally rides in the same line: the SAME 96 blocks of 4 MiB in the whole job, 96 / N per GPU
+    strong = [c for c in out["configs"] if c["scaling"] == "strong"]
+    assert len(strong) == 1 and strong[0]["blocks_per_gpu"] == 96 // world and strong[0]["block_size"] == 4 << 20
+    assert strong[0]["blocks_total"] == world * (96 // world) and strong[0]["blocks_checked"] == strong[0]["blocks_total"]
+    assert [p["rank"] for p in strong[0]["per_rank"]] == list(range(world)) and strong[0]["value"] > 0
     assert [p["rank"] for p in out["per_rank"]] == list(range(world))
     assert all(p["kernel_ms"] > 0 and p["gather_us"] > 0 for p in out["per_rank"])
     assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["cores"] == 1

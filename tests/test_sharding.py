@@ -53,3 +53,25 @@ def test_two_ranks_gather_sizes_and_offsets():
         assert sizes == want and offsets == want_off, rank
         seen.update(dict(hashes))
     assert sorted(seen) == list(range(n_blocks))
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher: the command it execs is the driver's own N > 1 form, and
+    on this GPU-less box the exec really happens — N ranks start under torch.distributed.run and each one says there is no device."""
+    import subprocess
+    import sys
+    sys.path.insert(0, util.ROOT)
+    import bench
+    cmd = bench.launcher_argv(4, ["--gpus", "4", "--steps", "2"])
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-5:] == [os.path.join(util.ROOT, "bench.py"), "--gpus", "4", "--steps", "2"]
+    if torch.cuda.is_available():
+        return
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--headline-only", "--no-cpu", "--blocks", "8"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=util.ROOT)
+    assert r.returncode != 0
+    err = r.stdout + r.stderr
+    assert "launch with torch.distributed.run" not in err and "disagree" not in err
+    assert "local_rank: 1" in err or "rank      : 1" in err or "rank: 1" in err.replace(" ", "").replace("rank:", "rank: "), err[-1500:]
