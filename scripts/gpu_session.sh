@@ -50,5 +50,16 @@ validate_slim)
   bash scripts/gpu_traffic.sh $TAG "10 262144 65536" "10 4194304 6656" "30 262144 16384" "21 262144 16384" > $O/traffic.log 2>&1
   grep -E "^L" $O/traffic.log | tee -a $O/summary.txt
   for l in 11 31 13 14 15 16 17 35 37 22 41 42; do timeout 300 tests/gpu_bench $l 262144 16384 2 50 1024 2>&1 | tail -1 | tee -a $O/summary.txt; done ;;
+rocprof_all)
+  # rocprofv3 kernel stats over EVERY BASELINE configuration of the bench line in one CSV
+  ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/rocprof -o bench -- python $R/bench.py --no-cpu --steps 3 --warmup 1 > $R/$O/bench_under_rocprof.json 2> $R/$O/rocprof.err; echo "rocprof rc=$?" ) | tee -a $O/summary.txt
+  find $O/rocprof -name "*kernel_stats.csv" -exec cp {} $O/rocprofv3_kernel_stats_bench_all_configs.csv \;
+  find $O/rocprof -name "*.csv" -size +1M -delete; find $O/rocprof -name "*.db" -delete
+  head -12 $O/rocprofv3_kernel_stats_bench_all_configs.csv ;;
+multirank)
+  # the N > 1 bench path on the one device: the pytest form (self-launch and torchrun), then a larger self-launched line
+  ( timeout 900 python -m pytest tests/test_bench_multirank.py -m gpu -q -x > $O/pytest_multirank.log 2>&1; echo "pytest multirank rc=$?" ) | tee -a $O/summary.txt; tail -5 $O/pytest_multirank.log
+  ( timeout 600 python bench.py --gpus 2 --transport host-bounce --steps 2 --warmup 1 --headline-only --strong --blocks 2048 --cpu-seconds 1 --cpu-all-seconds 0 > $O/bench_n2_selflaunch.json 2> $O/bench_n2.err; echo "bench n2 self-launch rc=$?" ) | tee -a $O/summary.txt
+  cut -c1-700 $O/bench_n2_selflaunch.json; tail -5 $O/bench_n2.err ;;
 *) echo "unknown mode $MODE"; exit 2 ;;
 esac
