@@ -62,7 +62,11 @@ struct LzStreams {
 // Phase profiling exists only in -DLZ_PROFILE builds of the library (lizard_amd/variants/prof), never in
 // the shipped liblizard_amd.so: LZ_PROF(st, k) adds the shader clocks since the previous mark to slot k.
 #ifdef LZ_PROFILE
+#ifdef LZ_HPROF_FINE      // the Huffman stage's fine marks take slots 0..4 (lz_huf.h): the parsers' marks there are dropped
+#define LZ_PROF(st, k) do { const u64 t_ = __builtin_readcyclecounter(); (st).prof[(k) < 5 ? 15 : (k)] += t_ - (st).prof_last; (st).prof_last = t_; (st).prof[15] = t_; } while (0)
+#else
 #define LZ_PROF(st, k) do { const u64 t_ = __builtin_readcyclecounter(); (st).prof[k] += t_ - (st).prof_last; (st).prof_last = t_; (st).prof[15] = t_; } while (0)
+#endif
 #else
 #define LZ_PROF(st, k) ((void)0)
 #endif
@@ -235,10 +239,15 @@ LZ_DEV void lz_seq_push(LzStreams& st, u32 L, u32 ml, u32 off)
 LZ_DEV void lz_seq_sizes(LzStreams& st)
 {
     u32 sum = 0;
-    for (u32 base = 0; base < st.nseq; base += 64u) {
-        const u32 i = base + lz_lane();
-        const u64 q = lz_ldq_s(&st.seq[i < st.nseq ? i : st.nseq - 1u]);
-        sum += i < st.nseq ? lz_lz4_record_bytes((u32)q & 0x3FFFFu, (u32)(q >> 18) & 0x3FFFFu) : 0u;
+    for (u32 base = 0; base < st.nseq; base += 256u) {        // four loads in flight: a step is one memory trip long
+        u64 q[4];
+        #pragma unroll
+        for (u32 k = 0; k < 4u; k++) { const u32 i = base + 64u * k + lz_lane(); q[k] = lz_ldq_s(&st.seq[i < st.nseq ? i : st.nseq - 1u]); }
+        #pragma unroll
+        for (u32 k = 0; k < 4u; k++) {
+            const u32 i = base + 64u * k + lz_lane();
+            sum += i < st.nseq ? lz_lz4_record_bytes((u32)q[k] & 0x3FFFFu, (u32)(q[k] >> 18) & 0x3FFFFu) : 0u;
+        }
     }
     st.nflags = st.nseq;
     st.nlit = st.lastLits + lz_wave_reduce_add(sum);
@@ -274,14 +283,40 @@ LZ_DEV void lz_copy_literal_runs(const u8* src, u8* litOut, u32 mySrc, u32 litAt
             if (n64 < 8u && sl < n64) lz_st8_s(litOut + o + sl, w1[g]);
         }
     }
-    // runs longer than 64 bytes (on the benchmark data the mean run is 76 bytes, so these are common): the
-    // rest of one run per iteration, 8 bytes per lane, the last piece pulled back to end at the run's end
-    for (u64 longRuns = lz_ballot(L > 64u); longRuns; longRuns &= longRuns - 1ull) {
-        const u32 j = lz_ctz64(longRuns);
-        const u32 nj = lz_readlane(L, j), a = lz_readlane(mySrc, j), o = lz_readlane(litAt, j);
-        for (u32 k = 64u + 8u * lane; k < nj; k += 512u) {
-            const u32 kk = k + 8u <= nj ? k : nj - 8u;
-            lz_st64_s(litOut + o + kk, lz_ld64_s(src + a + kk));
+    // runs longer than 64 bytes (on the benchmark data the mean run is 76 bytes, so these are common): the rest of them.
+    // Eight runs per iteration, their loads issued side by side before the first store: lanes 0..31 work on one run, lanes 32..63
+    // on the next, 16 bytes per lane (512 bytes of a run per pass), four such pairs.  One run at a time was a memory trip per long
+    // run — on the benchmark data ~14 of a step's 64 runs carry 4/5 of its literal bytes — and the largest single item of the
+    // consumers' encode pass (round 6).
+    for (u64 longRuns = lz_ballot(L > 64u); longRuns; ) {
+        const bool upper = lane >= 32u;
+        u32 nj[4], a[4], o[4];                                 // per lane: the run of my half in pair q
+        u32 most = 0;                                          // uniform: the longest of the (up to) eight runs
+        #pragma unroll
+        for (u32 q = 0; q < 4u; q++) {
+            const u32 j0 = longRuns ? lz_ctz64(longRuns) : 0u;
+            const u32 n0 = longRuns ? lz_readlane(L, j0) : 0u, a0 = lz_readlane(mySrc, j0), o0 = lz_readlane(litAt, j0);
+            longRuns &= longRuns - 1ull;                       // (0 stays 0)
+            const u32 j1 = longRuns ? lz_ctz64(longRuns) : 0u;
+            const u32 n1 = longRuns ? lz_readlane(L, j1) : 0u, a1 = lz_readlane(mySrc, j1), o1 = lz_readlane(litAt, j1);
+            longRuns &= longRuns - 1ull;
+            nj[q] = upper ? n1 : n0; a[q] = upper ? a1 : a0; o[q] = upper ? o1 : o0;
+            most = n0 > most ? n0 : most; most = n1 > most ? n1 : most;
+        }
+        const u32 sl = 16u * (lane & 31u);
+        for (u32 k0 = 64u; k0 < most; k0 += 512u) {            // uniform trip count
+            const u32 k = k0 + sl;
+            lz_u128 w[4];
+            #pragma unroll
+            for (u32 q = 0; q < 4u; q++) {
+                const u32 kk = k + 16u <= nj[q] ? k : nj[q] - 16u;          // the last piece is pulled back to end at the run's end (runs here are > 64 bytes)
+                if (k < nj[q]) w[q] = lz_ld128(src + a[q] + kk); else { w[q].lo = 0; w[q].hi = 0; }
+            }
+            #pragma unroll
+            for (u32 q = 0; q < 4u; q++) {
+                const u32 kk = k + 16u <= nj[q] ? k : nj[q] - 16u;
+                if (k < nj[q]) lz_st128(litOut + o[q] + kk, w[q]);
+            }
         }
     }
 }

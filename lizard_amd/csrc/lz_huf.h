@@ -28,16 +28,23 @@
 #define LZ_HPROF_ARG(st)
 #define LZ_HPROF(k) ((void)0)
 #endif
+// -DLZ_PROFILE -DLZ_HPROF_FINE: the tree / codes / header phase split up — slots 0 merge, 1 depths, 2 depth limit, 3 canonical codes,
+// 10 weight header alone (the parsers' marks 0..4 are dropped in such a build, lz_block.h)
+#if defined(LZ_PROFILE) && defined(LZ_HPROF_FINE)
+#define LZ_HPROF_F(k) LZ_HPROF(k)
+#else
+#define LZ_HPROF_F(k) ((void)0)
+#endif
 
 #define LZ_HUF_MAXBITS     12u    // HUF_TABLELOG_MAX, huf.h:118
 #define LZ_HUF_DEFAULTLOG  11u    // HUF_TABLELOG_DEFAULT, huf.h:119
 
 // LDS workspace (u32 words): 2 KiB per wave.  Only the wave-parallel steps use it (histogram, sort scatter, the two
 // index exchanges, the code table, the packer's ring); everything serial lives in registers (see LzV64 / LzV256).
-#define LZ_HUF_WS_COUNT    0u                          // u32[256]: histogram -> sort scatter -> depth / code-length exchange
-#define LZ_HUF_WS_CTAB     256u                        // u16[256]: val | nbBits << 12
-#define LZ_HUF_WS_STAGE    384u                        // packer staging ring
-#define LZ_HUF_STAGE_WORDS 104u
+#define LZ_HUF_WS_CTAB     0u                          // u16[256]: val | nbBits << 12
+#define LZ_HUF_WS_COUNT    128u                        // u32[256]: histogram -> sort scatter -> depth / code-length exchange
+#define LZ_HUF_WS_STAGE    128u                        // packer staging ring: OVER the histogram (dead once the code table exists) and the words behind it
+#define LZ_HUF_STAGE_WORDS 384u                        // 1 024 codes of <= 11 bits (HUF_compress2(.., 255, 11)) + 31 pending bits + two words of spill = 356
 #define LZ_HUF_WS_WORDS    512u                        // (the parser's 2 KiB round tag array aliases it)
 
 LZ_DEV u32 lz_highbit(u32 v) { return 31u - (u32)__builtin_clz(v); }   // BIT_highbit32, v != 0
@@ -103,29 +110,46 @@ LZ_DEV void lz_bv_align(LzBitV& b) { b.nb = (b.nb + 7u) & ~7u; lz_bv_flush(b); }
 LZ_DEV u32  lz_bv_bytes(const LzBitV& b) { return 4u * b.words + (b.nb >> 3); }    // after lz_bv_align
 
 // HUF_setMaxHeight, huf_compress.c:223-297, on the sorted leaves 0..lastNonNull: bits = code length by rank, leaf = count << 8 | symbol.
+// The reference's three walks over the ranks — cut the over-long codes (:233-238), skip the codes of exactly maxNbBits (:239), find
+// the last rank of every shorter length (:251-257) — are lane-parallel here (round 6: they were ~250 iterations of wave-uniform code
+// on register tables); the repayment loops (:259-292), a few dozen steps that depend on each other, stay wave-uniform.
+LZ_DEV int lz_v256_highest(u64 m0, u64 m1, u64 m2, u64 m3)      // highest position whose bit is set in the four 64-entry masks, -1 if none
+{
+    return m3 ? 255 - (int)lz_clz64(m3) : m2 ? 191 - (int)lz_clz64(m2) : m1 ? 127 - (int)lz_clz64(m1) : m0 ? 63 - (int)lz_clz64(m0) : -1;
+}
 LZ_DEV u32 lz_huf_set_max_height(const LzV256& leaf, LzV256& bits, u32 lastNonNull, u32 maxNbBits)
 {
     const u32 largestBits = bits.get(lastNonNull);
     if (largestBits <= maxNbBits) return largestBits;
     const u32 noSymbol = 0xF0F0F0F0u;
-    int totalCost = 0;
+    const u32 lane = lz_lane();
     const u32 baseCost = 1u << (largestBits - maxNbBits);
-    int n = (int)lastNonNull;
-    LzV64 rankLast; rankLast.r = noSymbol;                       // [LZ_HUF_MAXBITS + 2]
-    while (bits.get((u32)n) > maxNbBits) {
-        totalCost += (int)(baseCost - (1u << (largestBits - bits.get((u32)n))));
-        bits.set((u32)n, maxNbBits);
-        n--;
-    }
-    while (n >= 0 && bits.get((u32)n) == maxNbBits) n--;        // the reference stops on the barrier node (nbBits 0)
-    totalCost >>= (largestBits - maxNbBits);
+    int totalCost, n;
     {
-        u32 cur = maxNbBits;
-        for (int pos = n; pos >= 0; pos--) {
-            const u32 nb = bits.get((u32)pos);
-            if (nb >= cur) continue;
-            cur = nb;
-            rankLast.set(maxNbBits - cur, (u32)pos);
+        // :233-238 — from the last rank downwards while the code is too long: the ranks above the highest one that fits
+        const int stop = lz_v256_highest(lz_ballot(bits.r0 <= maxNbBits && lane <= lastNonNull), lz_ballot(bits.r1 <= maxNbBits && 64u + lane <= lastNonNull),
+                                         lz_ballot(bits.r2 <= maxNbBits && 128u + lane <= lastNonNull), lz_ballot(bits.r3 <= maxNbBits && 192u + lane <= lastNonNull));
+        u32 cost = 0;
+#define LZ_CUT(R, BASE) do { const bool cut_ = (int)((BASE) + lane) > stop && (BASE) + lane <= lastNonNull; \
+                             cost += cut_ ? baseCost - (1u << (largestBits - (cut_ ? (R) : largestBits))) : 0u; (R) = cut_ ? maxNbBits : (R); } while (0)
+        LZ_CUT(bits.r0, 0u); LZ_CUT(bits.r1, 64u); LZ_CUT(bits.r2, 128u); LZ_CUT(bits.r3, 192u);
+#undef LZ_CUT
+        totalCost = (int)lz_wave_reduce_add(cost);
+        // :239 — on to the last rank whose code is shorter than maxNbBits (-1: the reference stops on its barrier node)
+        n = lz_v256_highest(lz_ballot(bits.r0 != maxNbBits && (int)lane <= stop), lz_ballot(bits.r1 != maxNbBits && (int)(64u + lane) <= stop),
+                            lz_ballot(bits.r2 != maxNbBits && (int)(128u + lane) <= stop), lz_ballot(bits.r3 != maxNbBits && (int)(192u + lane) <= stop));
+    }
+    totalCost >>= (largestBits - maxNbBits);
+    // :251-257 — rankLast[maxNbBits - v] = the rank at which the walk from n downwards first sees a length <= v, if that length IS v:
+    // H(v) = highest rank <= n with a length <= v; the walk's running minimum drops to v there iff H(v) != H(v - 1).
+    LzV64 rankLast; rankLast.r = noSymbol;                       // [LZ_HUF_MAXBITS + 2]
+    {
+        int below = -1;                                          // H(v - 1); no code has length 0
+        for (u32 v = 1; v < maxNbBits; v++) {
+            const int h = lz_v256_highest(lz_ballot(bits.r0 <= v && (int)lane <= n), lz_ballot(bits.r1 <= v && (int)(64u + lane) <= n),
+                                          lz_ballot(bits.r2 <= v && (int)(128u + lane) <= n), lz_ballot(bits.r3 <= v && (int)(192u + lane) <= n));
+            if (h != below) rankLast.set(maxNbBits - v, (u32)h);
+            below = h;
         }
     }
     while (totalCost > 0) {
@@ -341,69 +365,103 @@ LZ_DEV u32 lz_huf_compress_weights(LzBitV& b, u32 wt4, u32 wtSize, const LzV64& 
 }
 
 // One 1X bitstream (huf_compress.c:427-470): symbols src[a..b) appended LAST -> FIRST, LSB first, then a
-// single '1'.  nbytes = ceil((bits+1)/8) is known from the size pass.  All lanes call; `stage` is LDS.
-LZ_DEV void lz_huf_pack_segment(const u8* src, u32 a, u32 b, u8* out, u32 nbytes, const u16* ctab, u32* stage)
+// single '1'.  Returns the stream's bytes, ceil((bits + 1) / 8) (uniform).  All lanes call; `stage` is LDS.
+// A step takes 1 024 symbols: lane l the 16 that follow 16 l in append order, i.e. the 16 bytes that END at src[hi] — one
+// 16-byte load, requested a step ahead — as four groups of four codes (<= 44 bits each: a u64).  One wave scan of the lanes'
+// bit counts per step, <= 12 ds_or per lane into the ring, whole dwords stored coalesced.  (Round 6: 256 symbols per step
+// cost one scan, one ring hand-over and three LDS waits per 256 symbols — a third of a consumer's time at level 30.)
+LZ_DEV void lz_huf_pack4(u32 w4, const u16* ctab, u64& acc, u32& len)
+{
+    const u32 e0 = ctab[w4 >> 24], e1 = ctab[(w4 >> 16) & 255u], e2 = ctab[(w4 >> 8) & 255u], e3 = ctab[w4 & 255u];
+    const u32 l0 = e0 >> 12, l1 = e1 >> 12, l2 = e2 >> 12, l3 = e3 >> 12;
+    const u32 p01 = (e0 & 0xFFFu) | ((e1 & 0xFFFu) << l0), p23 = (e2 & 0xFFFu) | ((e3 & 0xFFFu) << l2);     // <= 24 bits each
+    acc = (u64)p01 | ((u64)p23 << (l0 + l1));
+    len = l0 + l1 + l2 + l3;
+}
+LZ_DEV void lz_huf_stage_or(u32* stage, u32 pos, u64 acc, u32 len)
+{
+    if (len) {
+        const u32 w = pos >> 5, sh = pos & 31u;
+        const u32 lo = (u32)acc, hi32 = (u32)(acc >> 32);
+        const u32 w0 = lo << sh;
+        const u32 w1 = sh ? ((lo >> (32u - sh)) | (hi32 << sh)) : hi32;
+        const u32 w2 = sh ? (hi32 >> (32u - sh)) : 0u;
+        if (w0) lz_lds_atomic_or(&stage[w], w0);
+        if (w1) lz_lds_atomic_or(&stage[w + 1u], w1);
+        if (w2) lz_lds_atomic_or(&stage[w + 2u], w2);
+    }
+}
+LZ_DEV u32 lz_huf_pack_segment(const u8* src, u32 a, u32 b, u8* out, const u16* ctab, u32* stage)
 {
     const u32 lane = lz_lane();
+    constexpr u32 PER = 16u, STEP = 64u * PER;
     for (u32 i = lane; i < LZ_HUF_STAGE_WORDS; i += 64u) stage[i] = 0;
     lz_lds_sync();
     u32 cur = 0;            // uniform: bits pending in stage[0] (< 32)
     u32 wordsOut = 0;       // uniform: dwords already stored to `out`
     u32 remaining = b - a;  // uniform: symbols not yet appended; next to append is src[a + remaining - 1]
-    // my dword of a full step, requested one step ahead (the step itself is a chain of LDS trips: scan, or, store)
-    u32 wNext = (remaining >= 256u) ? lz_ld32(src + a + remaining - 4u - lane * 4u) : 0u;
+    // my 16 bytes of a full step, requested one step ahead (the step itself is a chain of LDS trips: lookups, scan, or, store)
+    u32 wn[4] = { 0, 0, 0, 0 };
+    if (remaining >= STEP) {
+        const u8* q = src + a + remaining - PER - lane * PER;
+        #pragma unroll
+        for (u32 g = 0; g < 4u; g++) wn[g] = lz_ld32(q + 4u * g);
+    }
     while (remaining > 0) {
-        // lane takes up to 4 symbols: src[hi-3 .. hi], appended in the order hi, hi-1, hi-2, hi-3
-        const u32 take = remaining < 256u ? remaining : 256u;
-        const u32 first = lane * 4u;                      // index (in append order) of my first symbol in this step
-        u64 acc = 0; u32 len = 0;
-        const u32 wCur = wNext;
-        if (remaining >= 512u) wNext = lz_ld32(src + a + remaining - 256u - 4u - lane * 4u);    // uniform condition
+        const u32 take = remaining < STEP ? remaining : STEP;
+        const u32 first = lane * PER;                     // index (in append order) of my first symbol in this step
+        u64 acc[4] = { 0, 0, 0, 0 }; u32 len[4] = { 0, 0, 0, 0 };
+        u32 wc[4];
+        #pragma unroll
+        for (u32 g = 0; g < 4u; g++) wc[g] = wn[g];
+        if (remaining >= 2u * STEP) {                     // uniform condition
+            const u8* q = src + a + remaining - STEP - PER - lane * PER;
+            #pragma unroll
+            for (u32 g = 0; g < 4u; g++) wn[g] = lz_ld32(q + 4u * g);
+        }
         if (first < take) {
-            const u32 cnt = take - first < 4u ? take - first : 4u;
-            const u32 hi = a + remaining - 1u - first;
-            if (cnt == 4u) {                                  // one dword load, four independent table lookups
-                const u32 w4 = take == 256u ? wCur : lz_ld32(src + hi - 3u);
-                const u32 e0 = ctab[w4 >> 24], e1 = ctab[(w4 >> 16) & 255u], e2 = ctab[(w4 >> 8) & 255u], e3 = ctab[w4 & 255u];
-                acc = (u64)(e0 & 0xFFFu);               len = e0 >> 12;
-                acc |= (u64)(e1 & 0xFFFu) << len;       len += e1 >> 12;
-                acc |= (u64)(e2 & 0xFFFu) << len;       len += e2 >> 12;
-                acc |= (u64)(e3 & 0xFFFu) << len;       len += e3 >> 12;
+            const u32 cnt = take - first < PER ? take - first : PER;
+            const u32 hi = a + remaining - 1u - first;    // my first symbol; the others sit below it
+            if (cnt == PER) {
+                if (take != STEP) {
+                    #pragma unroll
+                    for (u32 g = 0; g < 4u; g++) wc[g] = lz_ld32(src + hi - 15u + 4u * g);
+                }
+                #pragma unroll
+                for (u32 g = 0; g < 4u; g++) lz_huf_pack4(wc[3u - g], ctab, acc[g], len[g]);      // group g: src[hi - 4g] .. src[hi - 4g - 3]
             } else {
                 for (u32 j = 0; j < cnt; j++) {
-                    const u32 e = ctab[src[hi - j]];
-                    acc |= (u64)(e & 0xFFFu) << len;
-                    len += e >> 12;
+                    const u32 e = ctab[src[hi - j]], g = j >> 2;
+                    const u64 v = (u64)(e & 0xFFFu) << len[g];
+                    acc[0] |= g == 0 ? v : 0ull; acc[1] |= g == 1 ? v : 0ull; acc[2] |= g == 2 ? v : 0ull; acc[3] |= g == 3 ? v : 0ull;
+                    len[0] += g == 0 ? e >> 12 : 0u; len[1] += g == 1 ? e >> 12 : 0u; len[2] += g == 2 ? e >> 12 : 0u; len[3] += g == 3 ? e >> 12 : 0u;
                 }
             }
         }
-        const u32 off = lz_wave_scan_excl_add(len);
-        const u32 total = lz_readlane(off + len, 63u);
-        if (len) {
-            const u32 pos = cur + off, w = pos >> 5, sh = pos & 31u;
-            const u32 lo = (u32)acc, hi32 = (u32)(acc >> 32);
-            const u32 w0 = lo << sh;
-            const u32 w1 = sh ? ((lo >> (32u - sh)) | (hi32 << sh)) : hi32;
-            const u32 w2 = sh ? (hi32 >> (32u - sh)) : 0u;
-            if (w0) lz_lds_atomic_or(&stage[w], w0);
-            if (w1) lz_lds_atomic_or(&stage[w + 1u], w1);
-            if (w2) lz_lds_atomic_or(&stage[w + 2u], w2);
+        const u32 mine = len[0] + len[1] + len[2] + len[3];
+        const u32 off = lz_wave_scan_excl_add(mine);
+        const u32 total = lz_readlane(off + mine, 63u);
+        {
+            u32 pos = cur + off;
+            #pragma unroll
+            for (u32 g = 0; g < 4u; g++) { lz_huf_stage_or(stage, pos, acc[g], len[g]); pos += len[g]; }
         }
         lz_lds_sync();
         const u32 T = cur + total, full = T >> 5;
-        // store the completed dwords (<= 97 per step), coalesced
+        // store the completed dwords (<= 353 per step: 1 024 codes of at most 11 bits + the pending bits), coalesced
         for (u32 i = lane; i < full; i += 64u) lz_st32(out + 4u * (wordsOut + i), stage[i]);
         const u32 carry = stage[full];
         lz_lds_sync();
-        for (u32 i = lane; i < LZ_HUF_STAGE_WORDS; i += 64u) stage[i] = (i == 0) ? carry : 0u;
+        for (u32 i = lane; i < full + 3u; i += 64u) stage[i] = (i == 0) ? carry : 0u;
         lz_lds_sync();
         wordsOut += full; cur = T & 31u; remaining -= take;
     }
     // end mark + the last partial dword, byte by byte
     const u32 lastWord = stage[0] | (1u << cur);
-    const u32 done = 4u * wordsOut;
+    const u32 done = 4u * wordsOut, nbytes = done + ((cur + 1u + 7u) >> 3);
     if (lane < 4u && done + lane < nbytes) out[done + lane] = (u8)(lastWord >> (8u * lane));
     lz_lds_sync();
+    return nbytes;
 }
 
 // Lizard_writeStream for a Huffman candidate (lizard_compress.c:141-183) at `op`:
@@ -493,62 +551,103 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
         leaf.r2 = 128u + lane <= maxSym ? count[128u + lane] : 0u;
         leaf.r3 = 192u + lane <= maxSym ? count[192u + lane] : 0u;
         LZ_HPROF(9);                                           // rank sort
-        // ---- tree (huf_compress.c:334-376): the two-queue merge, heads of both queues kept in scalars ----
-        // internal node k stands for the reference's huffNode[256 + k]; parL / parN: parent (as k) of leaf rank i / of node k
-        LzV256 nodeC, parL, parN;
-        nodeC.r0 = nodeC.r1 = nodeC.r2 = nodeC.r3 = 0; parL = nodeC; parN = nodeC;
+        // ---- tree (huf_compress.c:334-376): the two-queue merge.  Internal node k stands for the reference's huffNode[256 + k].
+        // The serial loop only DECIDES: per node the sum of its two children and how many of them were leaves (0, 1, 2).  Both
+        // queues are consumed in order — leaves from the smallest upwards, nodes in the order they were made — so that count is
+        // all the tree there is: the parents of every leaf and node follow from prefix sums over it, lane-parallel, behind the loop
+        // (round 5 tracked both parent tables inside the loop: twice the instructions and a dozen branches per node).  A step is
+        // branch-free scalar code on the two heads of each queue (:357-360: a leaf is taken only when strictly smaller). ----
         const u32 kRoot = nonNull - 1u;
+        LzV256 T;                                              // by node: leaves among its two children
         {
             const u32 BAR = 1u << 31, BIG = 1u << 30;          // :351 barrier below the leaves, :350 nodes not made yet
-            int lowS = (int)nonNull;
-            u32 lowN = 0, nodeNb = 0;
-            {   // :344-347
-                const u32 c = (leaf.get((u32)lowS) >> 8) + (leaf.get((u32)lowS - 1u) >> 8);
-                nodeC.set(0, c); parL.set((u32)lowS, 0); parL.set((u32)lowS - 1u, 0);
-                nodeNb = 1; lowS -= 2;
-            }
-            // The queues move one way — leaves from rank lowS downwards, nodes from lowN upwards, new nodes at nodeNb upwards — so the
-            // 64 entries around each cursor ride in ONE register: an access is a v_readlane / a compare-and-select on that register
-            // instead of four of each with a scalar selection behind them (LzV256::get / ::set); a cursor that crosses into the next
-            // 64 entries writes its register back and takes the next (three times per table at most).
-            u32 chS = lowS >= 0 ? (u32)lowS >> 6 : 0u, chR = 0, chW = 0;         // chunks of the leaf cursor, the node read cursor, the node write cursor
-            u32 leafReg = leaf.reg(chS), parLReg = parL.reg(chS);
-            u32 nodeW = nodeC.r0, nodeR = 0, parNReg = parN.r0;
-            u32 curS = lowS >= 0 ? lz_readlane(leafReg, (u32)lowS & 63u) >> 8 : BAR;
-            u32 curN = lz_readlane(nodeW, 0u);
-            while (nodeNb <= kRoot) {                          // :353-369 (a leaf is taken only when strictly smaller)
-                u32 sum = 0;
-                for (u32 pick = 0; pick < 2u; pick++) {
-                    if (curS < curN) {
-                        sum += curS; parLReg = lz_writelane(parLReg, nodeNb, (u32)lowS & 63u); lowS--;
-                        if (lowS >= 0) {
-                            if (((u32)lowS & 63u) == 63u) { parL.putReg(chS, parLReg); chS--; leafReg = leaf.reg(chS); parLReg = parL.reg(chS); }
-                            curS = lz_readlane(leafReg, (u32)lowS & 63u) >> 8;
-                        } else curS = BAR;
-                    } else {
-                        sum += curN; parNReg = lz_writelane(parNReg, nodeNb, lowN & 63u); lowN++;
-                        if ((lowN & 63u) == 0u) { parN.putReg(chR, parNReg); chR++; parNReg = parN.reg(chR); if (chR < chW) nodeR = nodeC.reg(chR); }
-                        curN = lowN < nodeNb ? lz_readlane(chR == chW ? nodeW : nodeR, lowN & 63u) : BIG;
+            LzV256 A, Bq;                                      // leaf counts in ASCENDING order (i = nonNull - rank; BAR behind them); node counts (BIG = not made yet)
+            A.r0 = lane <= nonNull ? count[nonNull - lane] >> 8 : BAR;
+            A.r1 = 64u + lane <= nonNull ? count[nonNull - 64u - lane] >> 8 : BAR;
+            A.r2 = 128u + lane <= nonNull ? count[nonNull - 128u - lane] >> 8 : BAR;
+            A.r3 = 192u + lane <= nonNull ? count[nonNull - 192u - lane] >> 8 : BAR;
+            Bq.r0 = Bq.r1 = Bq.r2 = Bq.r3 = BIG;
+            T.r0 = T.r1 = T.r2 = T.r3 = 0;
+            u32 li = 0, ni = 0, nodeNb = 0;                    // next leaf, next node, the node being made
+            // The 64 entries around each cursor ride in one register: leaves read (chunk cA; chunk 4 = the barrier behind 256 leaves),
+            // nodes read (cR), nodes written (cW, live in Bw / Tw).  The loop runs in stretches that no cursor can leave its 64
+            // entries in — a step moves a read cursor by two at most — so a step of a stretch has no cursor test in it: two compares,
+            // their selects, one add, two v_writelane, four v_readlane.  Between stretches ONE step goes through the general accessors.
+            u32 cA = 0, cR = 0, cW = 0;
+            u32 Ac = A.r0, Br = BIG, Bw = BIG, Tw = 0;
+            u32 s0 = lz_readlane(Ac, 0u), s1 = lz_readlane(Ac, 1u), n0 = BIG, n1 = BIG;     // (nonNull >= 1: at least two leaves)
+#define LZ_MERGE_DECIDE()  const bool c1 = s0 < n0;                                                                    \
+                           const u32 x = c1 ? s1 : s0, y = c1 ? n0 : n1;  /* what the second pick chooses between */ \
+                           const bool c2 = x < y;                                                                      \
+                           const u32 sum = (c1 ? s0 : n0) + (c2 ? x : y);                                              \
+                           const u32 dl = (c1 ? 1u : 0u) + (c2 ? 1u : 0u)
+            while (nodeNb <= kRoot) {
+                u32 la = li & 63u, na = ni & 63u, wa = nodeNb & 63u;
+                u32 safe = kRoot + 1u - nodeNb;
+                { const u32 m = 64u - wa; safe = m < safe ? m : safe; }
+                { const u32 m = la <= 62u ? (62u - la) >> 1 : 0u; safe = m < safe ? m : safe; }
+                { const u32 m = na <= 62u ? (62u - na) >> 1 : 0u; safe = m < safe ? m : safe; }
+                safe = lz_uniform(safe);                       // (a scalar trip count: the min chain above tends to end up in a VGPR)
+                if (safe) {
+                    const bool live = cR == cW;                // the node heads sit in the register that is being written
+                    const u32 la0 = la, na0 = na;
+                    for (u32 it = 0; it < safe; it++) {
+                        LZ_MERGE_DECIDE();
+                        lz_writelane2(Bw, sum, Tw, dl, wa);
+                        wa++; la += dl; na += 2u - dl;
+                        const u32 from = live ? Bw : Br;
+                        s0 = lz_readlane(Ac, la); s1 = lz_readlane(Ac, la + 1u);
+                        n0 = lz_readlane(from, na); n1 = lz_readlane(from, na + 1u);
                     }
+                    li += la - la0; ni += na - na0; nodeNb += safe;
+                } else {
+                    LZ_MERGE_DECIDE();
+                    lz_writelane2(Bw, sum, Tw, dl, wa);
+                    li += dl; ni += 2u - dl; nodeNb++;
                 }
-                nodeW = lz_writelane(nodeW, sum, nodeNb & 63u);
-                if (lowN == nodeNb) curN = sum;                // the new node is the head of the node queue
-                nodeNb++;
-                if ((nodeNb & 63u) == 0u) { nodeC.putReg(chW, nodeW); chW++; nodeW = 0; if (chR < chW) nodeR = nodeC.reg(chR); }
+                if ((nodeNb & 63u) == 0u) { Bq.putReg(cW, Bw); T.putReg(cW, Tw); cW++; Bw = BIG; Tw = 0; }
+                if (!safe || (nodeNb & 63u) == 0u) {
+                    // re-seat the registers around the cursors; the heads through the general accessors
+                    cA = li >> 6; Ac = cA < 4u ? A.reg(cA) : BAR;
+                    cR = ni >> 6; Br = Bq.reg(cR);
+#define LZ_GETB(i) ((i) >= 256u ? BIG : ((i) >> 6) == cW ? lz_readlane(Bw, (i) & 63u) : Bq.get(i))
+                    s0 = li < 256u ? A.get(li) : BAR; s1 = li + 1u < 256u ? A.get(li + 1u) : BAR;
+                    n0 = LZ_GETB(ni); n1 = LZ_GETB(ni + 1u);
+#undef LZ_GETB
+                }
             }
-            parL.putReg(chS, parLReg); parN.putReg(chR, parNReg);
+#undef LZ_MERGE_DECIDE
+            T.putReg(cW, Tw);
+        }
+        LZ_HPROF_F(0);                                         // merge
+        // ---- parents (lane-parallel): node k = 64 j + lane took dl leaves and 2 - dl nodes; with Lb = leaves taken by the nodes before
+        // it, those are the leaves i = Lb, Lb + 1 (rank nonNull - i) and the nodes 2 k - Lb, ...  Node parents go to count[] in the form
+        // the pointer jumping wants (distance 1 << 8 | parent; the root points at itself), leaf parents to a u16 table behind it. ----
+        u16* const parLeaf = (u16*)(ws + LZ_HUF_WS_COUNT + 256u);      // [256], by rank
+        lz_lds_sync();                                         // the sorted leaves in count[] have been read
+        for (u32 j = 0; j < 4u; j++) count[64u * j + lane] = kRoot;   // (entries past the root are never looked at)
+        lz_lds_sync();
+        {
+            const u32 t[4] = { T.r0, T.r1, T.r2, T.r3 };
+            u32 carry = 0;
+            for (u32 j = 0; j < 4u; j++) {
+                const u32 exc = lz_wave_scan_excl_add(t[j]);
+                const u32 k = 64u * j + lane, lb = carry + exc, nb = 2u * k - lb;
+                carry += lz_readlane(exc + t[j], 63u);
+                if (k <= kRoot) {
+                    if (t[j] >= 1u) parLeaf[nonNull - lb] = (u16)k;
+                    if (t[j] == 2u) parLeaf[nonNull - lb - 1u] = (u16)k;
+                    if (t[j] <= 1u) count[nb] = (1u << 8) | k;
+                    if (t[j] == 0u) count[nb + 1u] = (1u << 8) | k;
+                }
+            }
         }
         // depths (:371-376).  Node depths by pointer jumping in LDS: word k = distance << 8 | ancestor, the root points at itself;
         // after r rounds every node has jumped 2^r levels, eight rounds cover any tree of 256 leaves.  Then the leaves.
         lz_lds_sync();
         {
             u32 w[4];
-            w[0] = parN.r0; w[1] = parN.r1; w[2] = parN.r2; w[3] = parN.r3;
-            for (u32 j = 0; j < 4u; j++) {
-                const u32 k = 64u * j + lane;
-                w[j] = k < kRoot ? (1u << 8) | w[j] : kRoot;     // (entries past the root are never looked at)
-                count[k] = w[j];
-            }
+            for (u32 j = 0; j < 4u; j++) w[j] = count[64u * j + lane];
             lz_lds_sync();
             for (u32 round = 0; round < 8u; round++) {
                 u32 nw[4];
@@ -559,12 +658,14 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
             }
         }
         LzV256 bits;                                           // by rank: code length (0 past nonNull)
-        bits.r0 = lane <= nonNull ? (count[parL.r0] >> 8) + 1u : 0u;
-        bits.r1 = 64u + lane <= nonNull ? (count[parL.r1] >> 8) + 1u : 0u;
-        bits.r2 = 128u + lane <= nonNull ? (count[parL.r2] >> 8) + 1u : 0u;
-        bits.r3 = 192u + lane <= nonNull ? (count[parL.r3] >> 8) + 1u : 0u;
+        bits.r0 = lane <= nonNull ? (count[parLeaf[lane]] >> 8) + 1u : 0u;
+        bits.r1 = 64u + lane <= nonNull ? (count[parLeaf[64u + lane]] >> 8) + 1u : 0u;
+        bits.r2 = 128u + lane <= nonNull ? (count[parLeaf[128u + lane]] >> 8) + 1u : 0u;
+        bits.r3 = 192u + lane <= nonNull ? (count[parLeaf[192u + lane]] >> 8) + 1u : 0u;
+        LZ_HPROF_F(1);                                         // depths
         u32 huffLog = lz_fse_optimal_tablelog(LZ_HUF_DEFAULTLOG, n, maxSym, 1u);   // HUF_optimalTableLog :66
         huffLog = lz_huf_set_max_height(leaf, bits, nonNull, huffLog);            // :379
+        LZ_HPROF_F(2);                                         // depth limit
         // ---- code length per symbol: through LDS by rank ----
         lz_lds_sync();
         count[lane] = bits.r0; count[64u + lane] = bits.r1; count[128u + lane] = bits.r2; count[192u + lane] = bits.r3;
@@ -607,6 +708,7 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
                 ctab[s] = (u16)code;
             }
         }
+        LZ_HPROF_F(3);                                         // canonical codes
         // ---- HUF_writeCTable (:132-165): weights of symbols 0..maxSym-1, FSE-compressed or as nibbles ----
         u32 hdr = 0;                                           // header size, 0 = reference error -> raw
         {
@@ -638,45 +740,56 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
         lz_lds_sync();                                         // ctab visible to every lane
         LZ_HPROF(10);                                          // tree / codes / header
         if (hdr != 0 && hdr + 12u < n) {                       // :556
-            // ---- exact stream sizes: sum of code lengths per segment (huf_compress.c:473-513) ----
+            // ---- accept or not (huf_compress.c:570, lizard_compress.c:157) BEFORE anything is encoded.  The four bitstreams hold
+            // B = sum over the symbols of count x code length bits — known from the histogram — plus an end mark each, rounded up to
+            // bytes each: their bytes lie in [ceil((B + 4) / 8), that + 3].  Only a stream whose fate the three bytes decide (rare)
+            // has its segments' code lengths summed up (huf_compress.c:473-513); round 5 did that for every stream (6 % of a
+            // level-30 consumer's time).  Accepted streams are packed one after the other, each where the one before ended. ----
             const u32 seg = (n + 3u) / 4u;
-            u32 segBytes[4], tot = hdr + 6u;
-            for (u32 k = 0; k < 4u; k++) {
-                const u32 a = k * seg, b = (k == 3u) ? n : (k + 1u) * seg;
-                u32 bits = 0;                                  // 4 symbols per lane per step (vector-memory cost is per instruction)
-                const u32 n4 = (b - a) & ~3u, n16 = (b - a) & ~1023u;
-                for (u32 i = lane * 4u; i < n16; i += 1024u) {     // four loads in flight
-                    u32 w[4];
-                    #pragma unroll
-                    for (u32 j = 0; j < 4u; j++) w[j] = lz_ld32(stream + a + i + j * 256u);
-                    #pragma unroll
-                    for (u32 j = 0; j < 4u; j++)
-                        bits += ((u32)ctab[w[j] & 255u] >> 12) + ((u32)ctab[(w[j] >> 8) & 255u] >> 12)
-                              + ((u32)ctab[(w[j] >> 16) & 255u] >> 12) + ((u32)ctab[w[j] >> 24] >> 12);
+            const u32 B = lz_wave_reduce_add(c4[0] * nb4[0] + c4[1] * nb4[1] + c4[2] * nb4[2] + c4[3] * nb4[3]);
+            const u32 lo = hdr + 6u + ((B + 4u + 7u) >> 3), hi = lo + 3u;
+            bool pack = hi < n - 1u && hi + hi / 8u + 512u < n;
+            if (!pack && lo < n - 1u && lo + lo / 8u + 512u < n) {
+                LZ_STAT(60);
+                u32 tot = hdr + 6u;
+                for (u32 k = 0; k < 4u; k++) {
+                    const u32 a = k * seg, b = (k == 3u) ? n : (k + 1u) * seg;
+                    u32 bits = 0;                                  // 4 symbols per lane per step (vector-memory cost is per instruction)
+                    const u32 n4 = (b - a) & ~3u, n16 = (b - a) & ~1023u;
+                    for (u32 i = lane * 4u; i < n16; i += 1024u) {     // four loads in flight
+                        u32 w[4];
+                        #pragma unroll
+                        for (u32 j = 0; j < 4u; j++) w[j] = lz_ld32(stream + a + i + j * 256u);
+                        #pragma unroll
+                        for (u32 j = 0; j < 4u; j++)
+                            bits += ((u32)ctab[w[j] & 255u] >> 12) + ((u32)ctab[(w[j] >> 8) & 255u] >> 12)
+                                  + ((u32)ctab[(w[j] >> 16) & 255u] >> 12) + ((u32)ctab[w[j] >> 24] >> 12);
+                    }
+                    for (u32 i = n16 + lane * 4u; i < n4; i += 256u) {
+                        const u32 w = lz_ld32(stream + a + i);
+                        bits += ((u32)ctab[w & 255u] >> 12) + ((u32)ctab[(w >> 8) & 255u] >> 12)
+                              + ((u32)ctab[(w >> 16) & 255u] >> 12) + ((u32)ctab[w >> 24] >> 12);
+                    }
+                    for (u32 i = a + n4 + lane; i < b; i += 64u) bits += (u32)ctab[stream[i]] >> 12;
+                    bits = lz_wave_reduce_add(bits);
+                    tot += (bits + 1u + 7u) >> 3;
                 }
-                for (u32 i = n16 + lane * 4u; i < n4; i += 256u) {
-                    const u32 w = lz_ld32(stream + a + i);
-                    bits += ((u32)ctab[w & 255u] >> 12) + ((u32)ctab[(w >> 8) & 255u] >> 12)
-                          + ((u32)ctab[(w >> 16) & 255u] >> 12) + ((u32)ctab[w >> 24] >> 12);
-                }
-                for (u32 i = a + n4 + lane; i < b; i += 64u) bits += (u32)ctab[stream[i]] >> 12;
-                bits = lz_wave_reduce_add(bits);
-                segBytes[k] = (bits + 1u + 7u) >> 3;
-                tot += segBytes[k];
+                pack = tot < n - 1u && tot + tot / 8u + 512u < n;
             }
-            LZ_HPROF(11);                                      // exact sizes
-            if (tot < n - 1u && tot + tot / 8u + 512u < n) {   // :570 and lizard_compress.c:157
+            LZ_HPROF(11);                                      // accept or not
+            if (pack) {
+                u8* q = payload + hdr + 6u;
+                u32 segBytes[4];
+                for (u32 k = 0; k < 4u; k++) {
+                    const u32 a = k * seg, b = (k == 3u) ? n : (k + 1u) * seg;
+                    segBytes[k] = lz_huf_pack_segment(stream, a, b, q, ctab, ws + LZ_HUF_WS_STAGE);
+                    q += segBytes[k];
+                }
                 if (lane == 0) {
                     lz_st16(payload + hdr, segBytes[0]); lz_st16(payload + hdr + 2, segBytes[1]); lz_st16(payload + hdr + 4, segBytes[2]);
                 }
                 lz_converge();
-                u8* q = payload + hdr + 6u;
-                for (u32 k = 0; k < 4u; k++) {
-                    const u32 a = k * seg, b = (k == 3u) ? n : (k + 1u) * seg;
-                    lz_huf_pack_segment(stream, a, b, q, segBytes[k], ctab, ws + LZ_HUF_WS_STAGE);
-                    q += segBytes[k];
-                }
-                csize = tot; accept = true;
+                csize = hdr + 6u + segBytes[0] + segBytes[1] + segBytes[2] + segBytes[3]; accept = true;
                 LZ_HPROF(12);                                  // bit packing
             }
         }

@@ -47,8 +47,6 @@ __global__ __launch_bounds__(1024) void lz_scan_kernel(const u32* sizes, u64* of
     if (t == 1023u) offsets[nBlocks] = part[1023];
 }
 
-struct __attribute__((packed, aligned(1))) lz_u128u { u32 x, y, z, w; };
-
 __global__ __launch_bounds__(256) void lz_gather_kernel(const u8* src, const u8* slots, u64 slotStride, const u32* sizes, const u64* offsets,
                                                         u8* packed, u32 nBlocks, u32 blockSize, u32 lastBlockSize, int mode)
 {
@@ -69,7 +67,7 @@ __global__ __launch_bounds__(256) void lz_gather_kernel(const u8* src, const u8*
     }
     const u32 bulk = len & ~15u;
     for (u32 i = threadIdx.x * 16u; i < bulk; i += 256u * 16u)
-        *reinterpret_cast<lz_u128u*>(out + i) = *reinterpret_cast<const lz_u128u*>(from + i);
+        lz_st128(out + i, lz_ld128(from + i));
     for (u32 i = bulk + threadIdx.x; i < len; i += 256u) out[i] = from[i];
 }
 

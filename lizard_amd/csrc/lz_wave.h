@@ -46,6 +46,14 @@ LZ_DEV u64 lz_uniform64(u64 v) { return (u64)lz_uniform((u32)v) | ((u64)lz_unifo
 // VALU ops, like s_mov m0 + v_writelane_b32, which needs M0 for its second scalar operand on gfx9.)
 LZ_DEV u32 lz_writelane(u32 v, u32 x, u32 dst) { return lz_lane() == dst ? x : v; }
 
+// Two register tables updated at one (wave-uniform) lane with wave-uniform values: s_mov m0 + two v_writelane_b32 (M0 as the lane
+// select is the one form in which gfx9 lets v_writelane take a second scalar operand) instead of two compare-and-select pairs.
+LZ_DEV void lz_writelane2(u32& a, u32 xa, u32& b, u32 xb, u32 dst)
+{
+    asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+                 : "+v"(a), "+v"(b) : "s"(xa), "s"(xb), "s"(dst) : "m0");
+}
+
 // arbitrary cross-lane gather (ds_bpermute_b32): every lane names its own source lane
 LZ_DEV u32 lz_shfl(u32 v, u32 srcLane) { return (u32)__builtin_amdgcn_ds_bpermute((int)(srcLane << 2), (int)v); }
 
@@ -197,6 +205,11 @@ LZ_DEV u64 lz_ld64(const u8* p) { return reinterpret_cast<const lz_u64u*>(p)->v;
 LZ_DEV void lz_st16(u8* p, u32 v) { reinterpret_cast<lz_u16u*>(p)->v = (u16)v; }
 LZ_DEV void lz_st32(u8* p, u32 v) { reinterpret_cast<lz_u32u*>(p)->v = v; }
 LZ_DEV void lz_st64(u8* p, u64 v) { reinterpret_cast<lz_u64u*>(p)->v = v; }
+// 16 bytes at once (one dwordx4 access, no alignment requirement either)
+struct lz_u128 { u64 lo, hi; };
+struct __attribute__((packed, aligned(1))) lz_u128u { u64 lo, hi; };
+LZ_DEV lz_u128 lz_ld128(const u8* p) { const lz_u128u* q = reinterpret_cast<const lz_u128u*>(p); lz_u128 r; r.lo = q->lo; r.hi = q->hi; return r; }
+LZ_DEV void lz_st128(u8* p, lz_u128 v) { lz_u128u* q = reinterpret_cast<lz_u128u*>(p); q->lo = v.lo; q->hi = v.hi; }
 // Two masked bit-field EXCHANGES in LDS in one round trip (ds_mskor_rtn_b32 twice, one wait): *pa = (*pa & ~ma) | va and the
 // same for b; oa / ob receive the dwords as they were before this lane's update.  The lanes of one DS atomic instruction that
 // hit the same dword are served in ascending lane order on gfx950 (tests/lds_atomic_order.hip: 0 violations in

@@ -103,6 +103,7 @@ LZ_DEV u64 lz_uniform64(u64 v) { return (u64)lz_uniform((u32)v) | ((u64)lz_unifo
 
 // x and dst are wave-uniform; no other lane's state is needed to emulate v_writelane
 LZ_DEV u32 lz_writelane(u32 v, u32 x, u32 dst) { return lz_lane() == dst ? x : v; }
+LZ_DEV void lz_writelane2(u32& a, u32 xa, u32& b, u32 xb, u32 dst) { if (lz_lane() == dst) { a = xa; b = xb; } }
 
 LZ_DEV u32 lz_shfl(u32 v, u32 srcLane)
 {
@@ -203,6 +204,9 @@ LZ_DEV u64 lz_ld64(const u8* p) { u64 v; memcpy(&v, p, 8); return v; }
 LZ_DEV void lz_st16(u8* p, u32 v) { u16 x = (u16)v; memcpy(p, &x, 2); }
 LZ_DEV void lz_st32(u8* p, u32 v) { memcpy(p, &v, 4); }
 LZ_DEV void lz_st64(u8* p, u64 v) { memcpy(p, &v, 8); }
+struct lz_u128 { u64 lo, hi; };
+LZ_DEV lz_u128 lz_ld128(const u8* p) { lz_u128 v; memcpy(&v, p, 16); return v; }
+LZ_DEV void lz_st128(u8* p, lz_u128 v) { memcpy(p, &v, 16); }
 LZ_DEV u64 lz_ld64_s(const u8* p) { return lz_ld64(p); }
 LZ_DEV u32 lz_ld32_s(const u8* p) { return lz_ld32(p); }
 LZ_DEV u8  lz_ld8_s(const u8* p) { return *p; }

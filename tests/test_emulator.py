@@ -130,6 +130,50 @@ def test_emulated_huffman_stream_vs_oracle():
     assert huffed > 10
 
 
+def test_emulated_huffman_streams_whose_fate_three_bytes_decide():
+    """Round 6: lz_put_stream_huf accepts or rejects a stream from the histogram alone (total code bits -> the four bitstreams' bytes
+    within three) and sums the segments' code lengths only when those three bytes decide.  Streams built to sit on the acceptance
+    rules of huf_compress.c:570 / lizard_compress.c:157: m incompressible bytes in front of 16-symbol bytes, m bisected to the
+    flip, then every m around it.  The exact pass (LZ_STAT 60) must be reached, on both sides of the flip, oracle-equal."""
+    import numpy as np
+    E = util.emulator()
+    E.emul_put_stream_huf.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_uint]
+    orc = util.oracle()
+    stats = (ctypes.c_ulonglong * 64)()
+
+    def want_of(data):
+        n = len(data); cap = n + (n >> 8) + 8 + 129 + 64
+        tmp = ctypes.create_string_buffer(cap)
+        c = orc.lzo_huf_compress(tmp, cap, data, n)
+        hdr = bytes([n & 255, (n >> 8) & 255, n >> 16])
+        if c != (1 << 64) - 1 and c > 0 and c + c // 8 + 512 < n:
+            return hdr + bytes([c & 255, (c >> 8) & 255, c >> 16]) + tmp.raw[:c], 1
+        return hdr + data, 0
+
+    reached = {0: 0, 1: 0}
+    for n, seed in ((6000, 1), (20001, 2), (50003, 3), (131000, 4)):
+        rs = np.random.RandomState(seed)
+        hi_part, lo_part = rs.randint(0, 256, n).astype(np.uint8), rs.randint(0, 16, n).astype(np.uint8)
+        make = lambda m: np.concatenate([hi_part[:m], lo_part[m:]]).tobytes()
+        a, b = 0, n                                            # accepted at a, not at b
+        assert want_of(make(a))[1] == 1 and want_of(make(b))[1] == 0
+        while b - a > 1:
+            m = (a + b) // 2
+            if want_of(make(m))[1]: a = m
+            else: b = m
+        for m in range(max(0, a - 12), min(n, a + 13)):
+            data = make(m)
+            want, wh = want_of(data)
+            E.emul_stats(stats, 1)
+            out = ctypes.create_string_buffer(n + 2048); h = ctypes.c_int(0)
+            r = E.emul_put_stream_huf(ctypes.create_string_buffer(data, n), n, out, ctypes.byref(h), m + 1)
+            assert (out.raw[:r], h.value) == (want, wh), (n, m)
+            E.emul_stats(stats, 1)
+            if stats[60]:
+                reached[wh] += 1
+    assert reached[0] > 0 and reached[1] > 0, reached
+
+
 def test_emulated_wave_helpers():
     """lz_count_fwd / lz_count_back / lz_count_both / lz_copy / scans against scalar definitions on buffers with
     planted repeats (short, around the 8-, 64- and 512-byte step sizes of the helpers, and long)."""
