@@ -263,10 +263,15 @@ LZ_DEV bool lz_fse_normalize(LzV64& norm, u32 tableLog, const LzV64& count, u32 
     return true;
 }
 
-// HUF_compressWeights, huf_compress.c:81-121: FSE-compress the weights of symbols 0..wtSize-1 into the register table
-// b.out (byte stream, LSB first).  wt4: lane l holds the weights of symbols 4l..4l+3, one per byte.  count[w]: number of
-// symbols with weight w.  Returns the compressed size, 0 = not compressible, 1 = all equal, 0xFFFFFFFF = reference error.
-LZ_DEV u32 lz_huf_compress_weights(LzBitV& b, u32 wt4, u32 wtSize, const LzV64& count)
+// HUF_compressWeights, huf_compress.c:81-121: FSE-compress the weights of symbols 0..wtSize-1 (byte stream, LSB first) into the
+// LDS words lds[256 ...] (lds: 384 words; the first 256 are work space).  wt4: lane l holds the weights of symbols 4l..4l+3, one per
+// byte.  count[w]: number of symbols with weight w.  Returns the compressed size, 0 = not compressible, 1 = all equal,
+// 0xFFFFFFFF = reference error.
+// The two interleaved FSE states are two chains of ~wtSize / 2 dependent steps: they run on LANES 0 and 1 side by side (round 6;
+// they were ~255 steps of wave-uniform code, 25 instructions each, 10 % of a level-30 consumer's time).  What a step needs of its
+// symbol (deltaNbBits, deltaFindState) is looked up for all steps at once beforehand, what it emits (value, bit count) goes to the
+// same LDS word; the bit stream is put together from those words by all lanes, like the code streams.
+LZ_DEV u32 lz_huf_compress_weights(LzBitV& b, u32 wt4, u32 wtSize, const LzV64& count, u32* lds)
 {
 #define LZ_WT(i) ((lz_readlane(wt4, (i) >> 2) >> (8u * ((i) & 3u))) & 255u)
     lz_bv_init(b);
@@ -338,30 +343,67 @@ LZ_DEV u32 lz_huf_compress_weights(LzBitV& b, u32 wt4, u32 wtSize, const LzV64& 
             }
         }
     }
-    // FSE_compress_usingCTable_generic, fse_compress.c:701-758 (+ fse.h:525-564): two interleaved states
+    // FSE_compress_usingCTable_generic, fse_compress.c:701-758 (+ fse.h:525-564): two interleaved states.  In emission order the
+    // steps are e = 0 .. wtSize - 3, step e encodes the weight of symbol wtSize - 3 - e; CState1 takes the even steps when wtSize is
+    // odd (its extra first step, :718-722) and the odd ones otherwise, CState2 the others; the states start from the last two weights.
     if (wtSize <= 2u) return 0;
-    const u32 pos = lz_bv_bytes(b);
-    long long st1, st2;
-    u32 i = wtSize;
-#define LZ_FSE_INIT2(S, sym) do { const u32 sy_ = (sym); const u32 db_ = dBits.get(sy_); const u32 nbo_ = (db_ + (1u << 15)) >> 16; \
-                                  const long long v_ = ((long long)nbo_ << 16) - db_; \
-                                  (S) = stateTable.get((u32)((v_ >> nbo_) + (int)dFind.get(sy_))); } while (0)
-#define LZ_FSE_ENC(S, sym) do { const u32 sy_ = (sym); const u32 nbo_ = (u32)(((S) + dBits.get(sy_)) >> 16); lz_bv_add(b, (u32)(S), nbo_); \
-                                (S) = stateTable.get((u32)(((S) >> nbo_) + (int)dFind.get(sy_))); } while (0)
-    if (wtSize & 1u) { LZ_FSE_INIT2(st1, LZ_WT(i - 1u)); LZ_FSE_INIT2(st2, LZ_WT(i - 2u)); i -= 3u; LZ_FSE_ENC(st1, LZ_WT(i)); }
-    else             { LZ_FSE_INIT2(st2, LZ_WT(i - 1u)); LZ_FSE_INIT2(st1, LZ_WT(i - 2u)); i -= 2u; }
-    bool useSt2 = true;
-    while (i > 0) { i--; if (useSt2) LZ_FSE_ENC(st2, LZ_WT(i)); else LZ_FSE_ENC(st1, LZ_WT(i)); useSt2 = !useSt2; }
-    lz_bv_add(b, (u32)st2, tableLog);
-    lz_bv_add(b, (u32)st1, tableLog);
-    lz_bv_add(b, 1u, 1u);                                     // BIT_closeCStream end mark
-    lz_bv_align(b);
-    b.out.set(b.words & 63u, (u32)b.acc);                     // the last, partial dword
-#undef LZ_FSE_INIT2
-#undef LZ_FSE_ENC
+    const u32 lane = lz_lane();
+    const u32 pos = lz_bv_bytes(b);                             // bytes of the NCount header in front of the stream
+    const u32 steps = wtSize - 2u;
+    u32* const arr = lds;                                       // [256] per step: deltaNbBits << 8 | deltaFindState, then value | bits << 8
+    u32* const hb = lds + 256u;                                 // [128] the header's bytes
+#define LZ_WTV(i) ((lz_shfl(wt4, (i) >> 2) >> (8u * ((i) & 3u))) & 255u)   /* weight of symbol i, i per lane */
+    for (u32 j = 0; j < 4u; j++) {
+        const u32 e = 4u * lane + j;
+        const u32 sy = LZ_WTV(e < steps ? wtSize - 3u - e : 0u);
+        const u32 db = lz_shfl(dBits.r, sy), df = lz_shfl(dFind.r, sy);
+        if (e < steps) arr[e] = (db << 8) | (df & 255u);
+    }
+    hb[lane] = 0; hb[64u + lane] = 0;
+    lz_lds_sync();
+    u32 S;                                                      // lane 0: CState1, lane 1: CState2 (the other lanes idle along)
+    const u32 par = (lane & 1u) ^ ((wtSize & 1u) ^ 1u);         // my steps are e = par, par + 2, ...
+    {   // FSE_initCState2, fse.h:538-549
+        const u32 sy = LZ_WTV(wtSize - 1u - par);
+        const u32 db = lz_shfl(dBits.r, sy);
+        const int df = (int)lz_shfl(dFind.r, sy);
+        const u32 nbo = (db + (1u << 15)) >> 16;
+        const u32 v = (nbo << 16) - db;
+        S = lz_shfl(stateTable.r, (u32)((int)(v >> nbo) + df) & 63u);
+    }
+    for (u32 e = par; e - par < steps; e += 2u) {              // uniform trip count; a lane whose last step does not exist idles through it
+        const bool mine = e < steps;
+        const u32 w = arr[mine ? e : 0u];
+        const u32 nbo = (S + (w >> 8)) >> 16;                   // FSE_encodeSymbol, fse.h:551-558
+        const u32 Snext = lz_shfl(stateTable.r, (u32)((int)(S >> nbo) + (int)(signed char)(w & 255u)) & 63u);
+        if (mine && lane < 2u) arr[e] = (S & ((1u << nbo) - 1u)) | (nbo << 8);
+        S = mine ? Snext : S;
+    }
+    lz_lds_sync();
+    // FSE_flushCState (:754-755) CState2 then CState1, and the end mark of BIT_closeCStream
+    if (lane < 2u) arr[steps + 1u - lane] = (S & ((1u << tableLog) - 1u)) | (tableLog << 8);
+    if (lane == 2u) arr[steps + 2u] = 1u | (1u << 8);
+    lz_lds_sync();
+    u32 acc = 0, len = 0;                                      // my four steps' bits: <= 24
+    for (u32 j = 0; j < 4u; j++) {
+        const u32 e = 4u * lane + j;
+        const u32 w = e < steps + 3u ? arr[e] : 0u;
+        acc |= (w & 255u) << len; len += w >> 8;
+    }
+    const u32 off = lz_wave_scan_excl_add(len);
+    const u32 total = lz_readlane(off + len, 63u);
+    if (len) {
+        const u32 at = 8u * pos + off, sh = at & 31u;
+        lz_lds_atomic_or(&hb[at >> 5], acc << sh);
+        if (sh && (acc >> (32u - sh))) lz_lds_atomic_or(&hb[(at >> 5) + 1u], acc >> (32u - sh));
+    }
+    // the NCount bytes: whole dwords in the register table, the rest still in the accumulator
+    if (lane < b.words) lz_lds_atomic_or(&hb[lane], b.out.r);
+    if (lane == b.words && b.nb) lz_lds_atomic_or(&hb[lane], (u32)b.acc);
+    lz_lds_sync();
+#undef LZ_WTV
 #undef LZ_WT
-    (void)pos;
-    return lz_bv_bytes(b);
+    return pos + ((total + 7u) >> 3);
 }
 
 // One 1X bitstream (huf_compress.c:427-470): symbols src[a..b) appended LAST -> FIRST, LSB first, then a
@@ -529,13 +571,19 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
         csize = 1; accept = true;
     } else if (largest > (n >> 7) + 1u) {                      // :545 otherwise "not compressible"
         // ---- sort: leaf[rank] = (count, symbol), descending count, ties ascending symbol (:305-325) ----
-        u32 rank[4] = { 0, 0, 0, 0 };
-        for (u32 t = 0; t <= maxSym; t++) {
-            const u32 ct = count[t];
-            for (u32 k = 0; k < 4u; k++) {
-                const u32 s = lane * 4u + k;
-                rank[k] += (ct > c4[k] || (ct == c4[k] && t < s)) ? 1u : 0u;
-            }
+        // One compare per pair: key = count << 8 | 255 - symbol is distinct per symbol and orders them exactly so; rank = keys above mine.
+        // (Symbols past maxSym have no count: their keys lie below every key of a symbol up to maxSym, so whole groups of four are read.)
+        u32 key[4], rank[4] = { 0, 0, 0, 0 };
+        for (u32 k = 0; k < 4u; k++) key[k] = (c4[k] << 8) | (255u - (lane * 4u + k));
+        for (u32 k = 0; k < 4u; k++) count[lane * 4u + k] = key[k];
+        lz_lds_sync();
+        for (u32 t = 0; t <= maxSym; t += 4u) {
+            u32 kt[4];
+            #pragma unroll
+            for (u32 j = 0; j < 4u; j++) kt[j] = count[t + j];
+            #pragma unroll
+            for (u32 j = 0; j < 4u; j++)
+                for (u32 k = 0; k < 4u; k++) rank[k] += kt[j] > key[k] ? 1u : 0u;
         }
         const u32 nonNull = lz_popc64(lz_ballot(c4[0] != 0)) + lz_popc64(lz_ballot(c4[1] != 0))
                           + lz_popc64(lz_ballot(c4[2] != 0)) + lz_popc64(lz_ballot(c4[3] != 0)) - 1u;   // last rank with a count (>= 1 here)
@@ -718,12 +766,14 @@ LZ_DEV u32 lz_put_stream_huf(u8* op, const u8* stream, u32 n, u32* ws, u32* huff
             wcount.set(wLast, wcount.get(wLast) - 1u);
             wcount.set(0, maxSym - nonNull);
             LzBitV b;
-            const u32 h = lz_huf_compress_weights(b, wt4, maxSym, wcount);
+            u32* const hlds = ws + LZ_HUF_WS_COUNT;                // the histogram's words and the leaf-parent table are free by now
+            const u32 h = lz_huf_compress_weights(b, wt4, maxSym, wcount, hlds);
             if (h == 0xFFFFFFFFu) hdr = 0;
             else if (h > 1u && h < maxSym / 2u) {
                 if (lane == 0) payload[0] = (u8)h;
                 lz_converge();
-                for (u32 k = 0; k < 4u; k++) if (4u * lane + k < h) payload[1u + 4u * lane + k] = (u8)(b.out.r >> (8u * k));
+                const u32 hw = hlds[256u + lane];
+                for (u32 k = 0; k < 4u; k++) if (4u * lane + k < h) payload[1u + 4u * lane + k] = (u8)(hw >> (8u * k));
                 hdr = h + 1u;
             }
             else if (maxSym > 128u) hdr = 0;                   // :158 ERROR(GENERIC)
