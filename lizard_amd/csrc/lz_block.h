@@ -959,6 +959,7 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
         else if (tabKind == LZ_TABKIND_GLOBAL) lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, pf32g, ws, st);
         else if (tabKind == LZ_TABKIND_LDS18)  lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, pf24c, ws, st);
         else                                   lz_parse_pricefast<HASHLOG, AUX>(src, pos, pos + part, pf32l, ws, st);
+        if constexpr (kLiz) lz_seq_sizes_liz(st);             // the stream sizes the priceFast parse does not keep (lz_seq_push_liz)
         {   // Huffman workspace: the wave's own (it doubles as the parser's tag array), or one borrowed from the workgroup's pool
             LzHufPool pool; pool.base = hufPoolMask ? hufPoolBase : (u32*)ws; pool.mask = hufPoolMask; pool.count = hufPoolCount; pool.stride = LZ_HUF_WS_WORDS;
             op += lz_write_subblock_seq<HUF, kLiz>(src, pos, pos + part, dst + op, st, pool);

@@ -147,20 +147,43 @@ template <int HASHLOG> LZ_DEV void lz_pf_tab_fresh(const LzTab24c& t)
 }
 
 // ---- sequence list (LIZv1): L < 2^18, ml < 2^18, off < 2^24 (0 = repeat the last offset) ----
-// Stream sizes exactly as the encoder will produce them (reference lib/lizard_compress_liz.h:43-165).
+// The parse pushes the list entry and nothing else (round 6; it used to keep the four stream sizes up to date with every sequence:
+// ~55 scalar instructions on the one chain that bounds the level, a quarter of what a sequence pushed from registers costs).  The
+// sizes the container's rules need (lizard_compress.c:201,228) are summed up over the finished list, 64 sequences per lane step.
 LZ_DEV void lz_seq_push_liz(LzStreams& st, u32 L, u32 ml, u32 off)
 {
-    const bool longOff = off >= LZ_16BIT_OFFSET;
     if (lz_lane() == 0) st.ring[st.nseq & (LZ_SEQ_RING - 1u)] = (u64)L | ((u64)ml << 18) | ((u64)off << 36);
     lz_converge();
-    const u32 m = longOff ? ml - LZ_MM_LONGOFF : ml;
-    const u32 mSat = longOff ? 31u : 15u;
     st.nseq += 1u;
-    st.nlit += lz_ext_len(L >= 7u, L - 7u) + L + lz_ext_len(m >= mSat, m - mSat);
-    st.nflags += (longOff && L > 0u) ? 2u : 1u;                              // liz.h:83-93: literal-only token in front
-    st.noff16 += (!longOff && off != 0u) ? 2u : 0u;
-    st.noff24 += longOff ? 3u : 0u;
     if ((st.nseq & (LZ_SEQ_RING - 1u)) == 0) lz_seq_flush(st);
+}
+// Stream sizes of a finished LIZv1 sequence list, exactly as the encoder will produce them (reference lib/lizard_compress_liz.h:43-165).
+LZ_DEV void lz_seq_sizes_liz(LzStreams& st)
+{
+    u32 lit = 0, fl = 0, o16 = 0, o24 = 0;
+    lz_wave_sync();                                              // the list's last burst
+    for (u32 base = 0; base < st.nseq; base += 256u) {           // four loads in flight: a step is one memory trip long
+        u64 q[4];
+        #pragma unroll
+        for (u32 k = 0; k < 4u; k++) { const u32 i = base + 64u * k + lz_lane(); q[k] = lz_ldq_s(&st.seq[i < st.nseq ? i : st.nseq - 1u]); }
+        #pragma unroll
+        for (u32 k = 0; k < 4u; k++) {
+            const u32 i = base + 64u * k + lz_lane();
+            const u32 L = (u32)q[k] & 0x3FFFFu, ml = (u32)(q[k] >> 18) & 0x3FFFFu, off = (u32)(q[k] >> 36);
+            const bool longOff = off >= LZ_16BIT_OFFSET;
+            const u32 m = longOff ? ml - LZ_MM_LONGOFF : ml, mSat = longOff ? 31u : 15u;
+            if (i < st.nseq) {
+                lit += lz_ext_len(L >= 7u, L - 7u) + L + lz_ext_len(m >= mSat, m - mSat);
+                fl += (longOff && L > 0u) ? 2u : 1u;             // liz.h:83-93: literal-only token in front
+                o16 += (!longOff && off != 0u) ? 2u : 0u;
+                o24 += longOff ? 3u : 0u;
+            }
+        }
+    }
+    st.nlit = st.lastLits + lz_wave_reduce_add(lit);
+    st.nflags = lz_wave_reduce_add(fl);
+    st.noff16 = lz_wave_reduce_add(o16);
+    st.noff24 = lz_wave_reduce_add(o24);
 }
 
 // Wave-parallel LIZv1 encoder (reference lib/lizard_compress_liz.h:43-179) over the sequence list of the sub-block
@@ -288,7 +311,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
     const u32 tagMask = (1u << TAGLOG) - 1u;
     u32 anchor = S;                                              // uniform
     u32 last_off = 0;                                            // uniform; Lizard_initBlock, lizard_compress.c:137
-    if (E - S < LZ_MFLIMIT + 1u) { st.lastLits = E - S; st.nlit += E - S; return; }
+    if (E - S < LZ_MFLIMIT + 1u) { st.lastLits = E - S; return; }
     const u32 mflimit = E - LZ_MFLIMIT, matchlimit = E - LZ_LASTLITERALS;
     u32 ip = S + 1u;                                             // uniform, pricefast.h:155
     constexpr bool kNarrow = !TAB::kSpecPut && LZ_PF_W0 < 64u;   // round width over a global-memory table: see the unchained form
@@ -519,7 +542,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
                 winfo = rep ? (LZ_PF_UNRESOLVED4 | (cb << 16) | (1u << 21)) : (hinfo & 0x1FFFFFu);
                 okMask = lz_ballot(rep || (hinfo >> 22) == 3u);  // known and passing
                 measuredOff = last_off;
-                LZ_PROF(st, 1);
+                LZ_PROF(st, 12);                                 // the next stretch's repeat-offset side again
             }
         }
         // settle the table for exactly the lanes that happened
@@ -548,7 +571,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
             if (back0 == LZ_PF_UNRESOLVED) back0 = lz_count_back(src, P, M, anchor);
             ip -= back0; ref -= back0; ml += back0;                                       // :176-182
         search:
-            LZ_PROF(st, 2);
+            LZ_PROF(st, 13);                                     // memory-based steps: winner lengths
             ml2 = 0;
             if (ip + ml >= mflimit) goto encode;                                          // :185
             start2 = ip + ml - 2u;
@@ -587,7 +610,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
                 if (ml2 < LZ_MM_LONGOFF && start2 - ref2 >= LZ_16BIT_OFFSET) ml2 = 0;
             }
         encode:
-            LZ_PROF(st, 2);
+            LZ_PROF(st, 13);
             {
                 const u32 off = ip - ref;
                 lz_seq_push_liz(st, ip - anchor, ml, off);
@@ -601,7 +624,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
     }
 tail:
     if (st.nseq & (LZ_SEQ_RING - 1u)) lz_seq_flush(st);
-    st.lastLits = E - anchor; st.nlit += E - anchor;             // liz.h:168-179
+    st.lastLits = E - anchor;                                    // liz.h:168-179
 }
 #else    // LZ_PF_CHAIN == 0: one sequence per round, lazy step from memory (rounds 2-3; A/B builds)
 template <int HASHLOG, int TAGLOG, class TAB>
@@ -614,7 +637,7 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
     const u32 tagMask = (1u << TAGLOG) - 1u;
     u32 anchor = S;                                              // uniform
     u32 last_off = 0;                                            // uniform; Lizard_initBlock, lizard_compress.c:137
-    if (E - S < LZ_MFLIMIT + 1u) { st.lastLits = E - S; st.nlit += E - S; return; }
+    if (E - S < LZ_MFLIMIT + 1u) { st.lastLits = E - S; return; }
     const u32 mflimit = E - LZ_MFLIMIT, matchlimit = E - LZ_LASTLITERALS;
     u32 ip = S + 1u;                                             // uniform, pricefast.h:155
     // Round width (see lz_parse_fast): rounds over a table in global memory start LZ_PF_W0 positions wide after a match and
@@ -826,6 +849,6 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
     }
 tail:
     if (st.nseq & (LZ_SEQ_RING - 1u)) lz_seq_flush(st);
-    st.lastLits = E - anchor; st.nlit += E - anchor;             // liz.h:168-179
+    st.lastLits = E - anchor;                                    // liz.h:168-179
 }
 #endif   // LZ_PF_CHAIN
