@@ -6,6 +6,7 @@
 // lizard_pipeline_host.c holds the pipelined host-buffer path, in C), and the single-process multi-device entry with an RCCL
 // all-gather of the per-block sizes (lizard_shard.h).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -47,12 +48,12 @@ void set_err(const char* fmt, const char* a, const char* b)
 
 // Memory budget (LizardGPU_setMemoryBudget): bytes of device memory the large buffers of ONE device's context may take (scratch
 // arenas, per-wave tables, hashChain work areas, the staging of the host-buffer entries); 0 = no cap.
-size_t g_budget = 0;
-size_t budget_room(const Ctx& c) { return !g_budget ? (size_t)-1 : (g_budget > c.devBytes ? g_budget - c.devBytes : 0); }
+std::atomic<size_t> g_budget{0};                              // read by every device's launches under their own locks, and without a lock by the getters
+size_t budget_room(const Ctx& c) { const size_t b = g_budget.load(std::memory_order_relaxed); return !b ? (size_t)-1 : (b > c.devBytes ? b - c.devBytes : 0); }
 int dev_alloc(Ctx& c, void** p, size_t bytes, const char* what)
 {
     if (bytes > budget_room(c)) {
-        snprintf(t_err, sizeof t_err, "%s: %zu bytes do not fit the memory budget of %zu bytes (%zu in use; LizardGPU_setMemoryBudget)", what, bytes, g_budget, c.devBytes);
+        snprintf(t_err, sizeof t_err, "%s: %zu bytes do not fit the memory budget of %zu bytes (%zu in use; LizardGPU_setMemoryBudget)", what, bytes, g_budget.load(), c.devBytes);
         return -LIZARDGPU_ERR_NOMEM;
     }
     LZ_HIP(hipMalloc(p, bytes));
@@ -116,9 +117,20 @@ struct Guard : LzGuard {
     ~Guard() { guard_release(*this); }
 };
 
+static int ctx_init_body(Ctx& c);
+void ctx_release(Ctx& c);
 int ctx_init(Ctx& c)
 {
     if (c.ready) return 0;
+    const int rc = ctx_init_body(c);
+    if (rc) {                                                   // a failure half way: what was taken goes back (and is no longer counted against the budget)
+        c.ready = 1; ctx_release(c);
+        (void)hipGetLastError();
+    }
+    return rc;
+}
+static int ctx_init_body(Ctx& c)
+{
     hipDeviceProp_t prop;
     LZ_HIP(hipGetDeviceProperties(&prop, c.device));
     c.cus = prop.multiProcessorCount;
@@ -238,7 +250,7 @@ int alloc_table_slots(Ctx& c, uint8_t** at, size_t* slotsAt, size_t stride, int 
     if (want * stride > budget_room(c) && ownArena) free_tables_except(c, kind);
     size_t slots = budget_room(c) / stride;
     if (slots > want) slots = want;
-    if (!slots) { snprintf(t_err, sizeof t_err, "%s: not one table of %zu bytes fits the memory budget of %zu bytes (%zu in use)", what, stride, g_budget, c.devBytes); return -LIZARDGPU_ERR_NOMEM; }
+    if (!slots) { snprintf(t_err, sizeof t_err, "%s: not one table of %zu bytes fits the memory budget of %zu bytes (%zu in use)", what, stride, g_budget.load(), c.devBytes); return -LIZARDGPU_ERR_NOMEM; }
     const int rc = dev_alloc(c, (void**)at, slots * stride, what);
     if (rc) return rc;
     *slotsAt = slots;
@@ -337,18 +349,26 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
     }
     // extra arenas that no launch has asked for in a while go back (64 launches on the context's own arena, all of theirs finished)
     if (ar) c.idleLaunches = 0;
-    else if (c.nExtra && ++c.idleLaunches >= 64) {
+    else if (c.nExtra && smallLaunch && !hcLevel && ++c.idleLaunches >= 64) {   // (launches that could have asked for one: large and hashChain launches say nothing about the small streams)
         bool idle = true;
         for (int i = 0; i < c.nExtra; i++) if (c.extra[i].timed && hipEventQuery(c.extra[i].ev1) != hipSuccess) idle = false;
         (void)hipGetLastError();
         if (idle) free_extra_arenas(c);
         c.idleLaunches = 0;
     }
-    uint8_t** const tablesAt = ar ? &ar->tables : &c.tables;
-    uint8_t** const pfTablesAt = ar ? &ar->pfTables : &c.pfTables;
-    size_t* const tablesSlotsAt = ar ? &ar->tablesSlots : &c.tablesSlots;
-    size_t* const pfSlotsAt = ar ? &ar->pfSlots : &c.pfSlots;
+    uint8_t** tablesAt = ar ? &ar->tables : &c.tables;
+    uint8_t** pfTablesAt = ar ? &ar->pfTables : &c.pfTables;
+    size_t* tablesSlotsAt = ar ? &ar->tablesSlots : &c.tablesSlots;
+    size_t* pfSlotsAt = ar ? &ar->pfSlots : &c.pfSlots;
     if (ar) { a.scratch = ar->scratch; a.counter = ar->counter; }
+    // An extra arena whose tables do not fit the memory budget any more (the hashChain work areas or the context's own tables took
+    // the room): the launch goes to the context's own arena after all — it waits for the launch that holds it, and may give up
+    // what other levels left behind (ownArena) — instead of failing where it would have succeeded on a quiet device.
+    auto own_arena_after_all = [&]() {
+        (void)hipGetLastError();
+        ar = nullptr; a.scratch = c.scratch; a.counter = c.counter;
+        tablesAt = &c.tables; pfTablesAt = &c.pfTables; tablesSlotsAt = &c.tablesSlots; pfSlotsAt = &c.pfSlots;
+    };
     if (hcLevel) {
         // per wave: bins, links, and 6 bytes + 1 bit per block position (chain, packed chain words, hit bits) — 10 bytes at levels
         // 16/17/37/38, whose first searches are decided ahead of the parse (best[], the LAST array of the slot: the other levels'
@@ -366,7 +386,7 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
             LZ_HIP(hipMemGetInfo(&freeB, &totalB));
             size_t budget = freeB / 2u;
             if (budget > ((size_t)128 << 30)) budget = (size_t)128 << 30;
-            if (g_budget) {                                      // LizardGPU_setMemoryBudget: what other levels left behind goes first
+            if (g_budget.load(std::memory_order_relaxed)) {      // LizardGPU_setMemoryBudget: what other levels left behind goes first
                 if (budget_room(c) < (size_t)c.cus * LZ_MAX_WAVES * slotBytes) free_tables_except(c, 3);
                 if (budget > budget_room(c)) budget = budget_room(c);
             }
@@ -387,9 +407,11 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
         }
         a.tables = c.hcSlots; a.tableStride = c.hcSlotBytes; a.tableSlots = (u32)c.hcNSlots;
     } else if (lv == 11 || lv == 31 || lv == 22 || lv == 42) {
+        if (!*tablesAt && ar && alloc_table_slots(c, tablesAt, tablesSlotsAt, LZ_TABWIDE_BYTES(18), 1, false, "tables of levels 11/31/22/42")) own_arena_after_all();
         if (!*tablesAt && (rc = alloc_table_slots(c, tablesAt, tablesSlotsAt, LZ_TABWIDE_BYTES(18), 1, !ar, "tables of levels 11/31/22/42"))) return rc;
         a.tables = *tablesAt; a.tableStride = LZ_TABWIDE_BYTES(18); a.tableSlots = (u32)*tablesSlotsAt;
     } else if (!((lv == 10 || lv == 30) && LZ_FAST12_SPLIT)) {             // (the producer / consumer form keeps every table in LDS)
+        if (!*pfTablesAt && ar && alloc_table_slots(c, pfTablesAt, pfSlotsAt, LZ_PF_SLOT_BYTES, 2, false, "tables of levels 21/41")) own_arena_after_all();
         if (!*pfTablesAt && (rc = alloc_table_slots(c, pfTablesAt, pfSlotsAt, LZ_PF_SLOT_BYTES, 2, !ar, "tables of levels 21/41"))) return rc;
         a.tables = *pfTablesAt; a.tableStride = LZ_PF_SLOT_BYTES; a.tableSlots = (u32)*pfSlotsAt;
     }
@@ -524,15 +546,12 @@ static void release_all_contexts(size_t newBudget, bool setBudget)
 {
     int saved = -1;
     if (hipGetDevice(&saved) != hipSuccess) saved = -1;
-    for (int d = 0; d < LZ_MAX_DEVICES; d++) {
-        Ctx& c = g_ctx[d];
-        lzk_combiner_quiesce(&c);                       // no batch of one-block callers is between its launch and its copy-out
-        pthread_mutex_lock(&c.mu);
-        ctx_release(c);
-        if (setBudget && d == 0) g_budget = newBudget;  // (under a context lock: launches read it under theirs)
-        pthread_mutex_unlock(&c.mu);
-        lzk_combiner_resume(&c);
-    }
+    // every context is quiesced and locked BEFORE the budget changes, and released under the new one: no launch on any device
+    // runs with holdings counted against the old budget while it reads the new (round 5 stored it under context 0's lock alone)
+    for (int d = 0; d < LZ_MAX_DEVICES; d++) { lzk_combiner_quiesce(&g_ctx[d]); pthread_mutex_lock(&g_ctx[d].mu); }
+    if (setBudget) g_budget.store(newBudget, std::memory_order_relaxed);
+    for (int d = 0; d < LZ_MAX_DEVICES; d++) ctx_release(g_ctx[d]);
+    for (int d = LZ_MAX_DEVICES - 1; d >= 0; d--) { pthread_mutex_unlock(&g_ctx[d].mu); lzk_combiner_resume(&g_ctx[d]); }
     if (saved >= 0) (void)hipSetDevice(saved);
 }
 
@@ -546,14 +565,18 @@ int LizardGPU_setMemoryBudget(size_t bytes)
 {
     t_err[0] = 0;
     if (bytes) {
-        int dev = selected_device(), count = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || dev >= count || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        int count = 0, cus = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) count = 0;
+        for (int d = 0; d < count; d++) {                   // the budget holds for every device: the floor is the largest one's
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, d) == hipSuccess && prop.multiProcessorCount > cus) cus = prop.multiProcessorCount;
+        }
+        if (!cus) {
             (void)hipGetLastError();
             snprintf(t_err, sizeof t_err, "no HIP device visible");
             return -LIZARDGPU_ERR_NO_DEVICE;
         }
-        const size_t floor_ = (size_t)prop.multiProcessorCount * kScratchBytes + ((size_t)256 << 20);
+        const size_t floor_ = (size_t)cus * kScratchBytes + ((size_t)256 << 20);
         if (bytes < floor_) {
             snprintf(t_err, sizeof t_err, "LizardGPU_setMemoryBudget(%zu): below the minimum of %zu bytes (one scratch arena of %zu bytes + 256 MiB)", bytes, floor_, floor_ - ((size_t)256 << 20));
             return -LIZARDGPU_ERR_ARG;
@@ -563,7 +586,7 @@ int LizardGPU_setMemoryBudget(size_t bytes)
     return 0;
 }
 
-size_t LizardGPU_memoryBudget(void) { return g_budget; }
+size_t LizardGPU_memoryBudget(void) { return g_budget.load(std::memory_order_relaxed); }
 
 size_t LizardGPU_memoryInUse(void)
 {
@@ -636,7 +659,12 @@ int    lzk_dev_alloc(LzCtx* c, void** p, size_t bytes)
     return dev_alloc(*c, p, bytes, "staging buffer");
 }
 void   lzk_dev_free(LzCtx* c, void* p, size_t bytes) { dev_free(*c, p, bytes); }
-size_t lzk_budget(void) { return g_budget; }
+size_t lzk_budget(void) { return g_budget.load(std::memory_order_relaxed); }
+size_t lzk_budget_room_for_staging(const LzCtx* c)
+{
+    const size_t b = g_budget.load(std::memory_order_relaxed), arena = (size_t)c->cus * kScratchBytes;
+    return !b ? (size_t)-1 : (b > arena ? b - arena : 0);
+}
 LzCtx* lzk_ctx_peek(void)
 {
     int count = 0;

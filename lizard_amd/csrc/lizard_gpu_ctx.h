@@ -104,6 +104,7 @@ int   lzk_ctx_init(LzCtx* c);
 int   lzk_dev_alloc(LzCtx* c, void** p, size_t bytes);
 void  lzk_dev_free(LzCtx* c, void* p, size_t bytes);
 size_t lzk_budget(void);                                    /* 0 = none */
+size_t lzk_budget_room_for_staging(const LzCtx* c);         /* (size_t)-1 = no budget; else what the budget leaves beside the context's scratch arena */
 int   lzk_clamp_level(int level);
 /* the block kernels over nBlocks blocks resident at d_src (launcher of LizardGPU_compressBlocks_device); k0 / k1 (may be NULL)
  * are recorded around the kernel; d_srcSizes / d_srcOffsets (may be NULL): a ragged batch, block b = d_srcSizes[b] bytes at d_src + d_srcOffsets[b] */

@@ -104,7 +104,7 @@ static int is_pinned_host(const void* p)
 }
 
 static size_t g_chunk_bytes = 0;                           /* host pipeline chunk (input bytes), 0 = not read yet */
-static size_t chunk_bytes(void)
+static size_t chunk_bytes(const LzCtx* ctx)
 {
     if (!g_chunk_bytes) {
         const char* e = getenv("LIZARDGPU_CHUNK_MB");
@@ -112,11 +112,12 @@ static size_t chunk_bytes(void)
         if (mb < 1 || mb > 65536) mb = 256;                  /* measured on a 4 GiB job: 256 MiB 37 GB/s, 512 MiB 26, 1 GiB 23 (fill and drain of the pipeline) */
         g_chunk_bytes = mb << 20;
     }
-    {   /* under a memory budget (LizardGPU_setMemoryBudget) the three stages' device buffers — about 3 x 3 chunks — take a sixth of it */
-        const size_t b = lzk_budget();
-        if (b) {
-            size_t c = (b / 64) & ~(((size_t)1 << 20) - 1);
-            if (c < ((size_t)8 << 20)) c = (size_t)8 << 20;
+    {   /* under a memory budget (LizardGPU_setMemoryBudget) the three stages' device buffers — input, slots and packed output each,
+         * about 3 x 3 chunks — must fit what the budget leaves beside the scratch arena: a sixteenth of that room per chunk */
+        const size_t room = lzk_budget_room_for_staging(ctx);
+        if (room != (size_t)-1) {
+            size_t c = (room / 16) & ~(((size_t)1 << 20) - 1);
+            if (c < ((size_t)4 << 20)) c = (size_t)4 << 20;
             if (c < g_chunk_bytes) return c;
         }
     }
@@ -252,7 +253,7 @@ static int run_host_job_inner(LzCtx* c, const HostJob* j)
     memset(&p, 0, sizeof p);
     pthread_mutex_init(&p.mu, NULL); pthread_cond_init(&p.cv, NULL);
     p.c = c; p.j = j;
-    p.perChunk = chunk_bytes() / j->blockSize;
+    p.perChunk = chunk_bytes(c) / j->blockSize;
     if (p.perChunk == 0) p.perChunk = 1;
     p.nChunks = (j->nBlocks + p.perChunk - 1) / p.perChunk;
     p.srcPinned = is_pinned_host(j->src);

@@ -52,6 +52,7 @@ LzCtx* lzk_ctx_peek(void) { return &g_c; }
 int   lzk_dev_alloc(LzCtx* c, void** p, size_t n) { (void)c; *p = malloc(n ? n : 1); return *p ? 0 : -LIZARDGPU_ERR_NOMEM; }
 void  lzk_dev_free(LzCtx* c, void* p, size_t n) { (void)c; (void)n; free(p); }
 size_t lzk_budget(void) { return 0; }
+size_t lzk_budget_room_for_staging(const LzCtx* c) { (void)c; return (size_t)-1; }
 int LizardGPU_levelSupported(int level) { return lzo_level_supported(level); }
 /* a "launch": every block of the ragged batch through the oracle, then the latency of a one-wave-per-block kernel */
 int lzk_launch(LzCtx* c, const void* d_src, size_t nBlocks, size_t blockSize, size_t lastBlockSize, void* d_dst, size_t dstStride,

@@ -84,3 +84,57 @@ def test_degraded_calls_are_counted(L):
     assert L.LizardGPU_degradedCalls() == n0 + 2
     assert lib.Lizard_compress(data, dst, len(data), 200000, 10) > 0         # a supported level is not counted
     assert L.LizardGPU_degradedCalls() == n0 + 2
+
+
+@pytest.mark.gpu
+def test_host_path_with_many_chunks_at_the_smallest_budget(L):
+    """at the smallest budget LizardGPU_setMemoryBudget accepts (one scratch arena + 256 MiB) the host pipeline's three
+    stages must still fit: its chunks are sized from the room the budget leaves beside the arena (a sixteenth each), not from the
+    budget as a whole.  ~100 MiB of blocks = more than three chunks of 16 MiB; every block against the oracle; and small launches of
+    a table level on a second stream while the context's own tables hold the room fall back to the context's arena instead of
+    failing (lizard_gpu.hip, own_arena_after_all)."""
+    import torch
+    from lizard_amd import api
+    L.LizardGPU_residentWaves.restype = C.c_int
+    cus = L.LizardGPU_residentWaves() // 13
+    floor = cus * 16 * 5 * (131072 + 32) + (256 << 20)                       # one scratch arena (16 slots of 5 padded sub-blocks per CU) + 256 MiB
+    assert L.LizardGPU_setMemoryBudget(floor - 1) < 0
+    assert L.LizardGPU_setMemoryBudget(floor) == 0
+    bs, nb = 262144, 400
+    data = b"".join(util.datagen(bs, 0.5, 0.0, 5000 + b) for b in range(nb))
+    outs = api.compress_blocks(data, bs, 10)
+    assert len(outs) == nb
+    for b in range(0, nb, 7):
+        assert outs[b] == util.oracle_compress(data[b * bs:(b + 1) * bs], 10), b
+    assert L.LizardGPU_memoryInUse() <= floor
+    assert L.LizardGPU_setMemoryBudget(0) == 0
+    # An extra arena whose tables no longer fit: room for two scratch arenas and 300 MiB.  Two streams of small table-less launches
+    # (level 10) make the second arena; level 11's tables then take the rest of the room on the context's own arena; a small level-11
+    # launch that is routed to the extra arena finds no room for ITS tables and must run on the context's own arena instead of failing.
+    arena = floor - (256 << 20)
+    assert L.LizardGPU_setMemoryBudget(2 * arena + (300 << 20)) == 0
+    L.LizardGPU_arenasInUse.restype = C.c_int
+    src = torch.from_numpy(np.frombuffer(data[:64 * bs], dtype=np.uint8).copy()).cuda()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(3):                                                       # (the second launch must find the first still running)
+        with torch.cuda.stream(s1):
+            api.compress_blocks_device(src, bs, 10)
+        with torch.cuda.stream(s2):
+            api.compress_blocks_device(src, bs, 10)
+    torch.cuda.synchronize()
+    assert L.LizardGPU_arenasInUse() == 2
+    with torch.cuda.stream(s1):
+        first = api.compress_blocks_device(src, bs, 11)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            a = api.compress_blocks_device(src, bs, 11)
+        with torch.cuda.stream(s2):
+            b2 = api.compress_blocks_device(src[:8 * bs], bs, 11)            # round 5: LIZARDGPU_ERR_NOMEM here
+        torch.cuda.synchronize()
+        assert torch.equal(a[1], first[1]) and torch.equal(b2[1], first[1][:8])
+    want = util.oracle_compress(data[:bs], 11)
+    assert int(b2[1][0]) == len(want) and b2[0][:len(want)].cpu().numpy().tobytes() == want
+    assert L.LizardGPU_memoryInUse() <= 2 * arena + (300 << 20)
+    assert L.LizardGPU_setMemoryBudget(0) == 0
