@@ -259,6 +259,9 @@ LZ_DEV void lz_seq_sizes(LzStreams& st)
 // sub-lane (the last piece is pulled back to end exactly at the run's end; overlapping pieces rewrite identical
 // bytes), shorter runs one byte per sub-lane.  All loads of the step are issued before the first store (loads and
 // stores return through one in-order counter on gfx950).  Lanes without a sequence pass L = 0.
+// PAIRS: long runs in flight per iteration of the loop at the end, two per pair: 4 in the consumers of lz_split.h (registers to spare),
+// 2 in the one-wave kernels, which sit at the 128-VGPR limit of a 16-wave workgroup.
+template <int PAIRS>
 LZ_DEV void lz_copy_literal_runs(const u8* src, u8* litOut, u32 mySrc, u32 litAt, u32 L)
 {
     const u32 lane = lz_lane();
@@ -290,10 +293,10 @@ LZ_DEV void lz_copy_literal_runs(const u8* src, u8* litOut, u32 mySrc, u32 litAt
     // consumers' encode pass (round 6).
     for (u64 longRuns = lz_ballot(L > 64u); longRuns; ) {
         const bool upper = lane >= 32u;
-        u32 nj[4], a[4], o[4];                                 // per lane: the run of my half in pair q
-        u32 most = 0;                                          // uniform: the longest of the (up to) eight runs
+        u32 nj[PAIRS], a[PAIRS], o[PAIRS];                                 // per lane: the run of my half in pair q
+        u32 most = 0;                                          // uniform: the longest of the (up to) 2 x PAIRS runs
         #pragma unroll
-        for (u32 q = 0; q < 4u; q++) {
+        for (u32 q = 0; q < (u32)PAIRS; q++) {
             const u32 j0 = longRuns ? lz_ctz64(longRuns) : 0u;
             const u32 n0 = longRuns ? lz_readlane(L, j0) : 0u, a0 = lz_readlane(mySrc, j0), o0 = lz_readlane(litAt, j0);
             longRuns &= longRuns - 1ull;                       // (0 stays 0)
@@ -306,14 +309,14 @@ LZ_DEV void lz_copy_literal_runs(const u8* src, u8* litOut, u32 mySrc, u32 litAt
         const u32 sl = 16u * (lane & 31u);
         for (u32 k0 = 64u; k0 < most; k0 += 512u) {            // uniform trip count
             const u32 k = k0 + sl;
-            lz_u128 w[4];
+            lz_u128 w[PAIRS];
             #pragma unroll
-            for (u32 q = 0; q < 4u; q++) {
+            for (u32 q = 0; q < (u32)PAIRS; q++) {
                 const u32 kk = k + 16u <= nj[q] ? k : nj[q] - 16u;          // the last piece is pulled back to end at the run's end (runs here are > 64 bytes)
                 if (k < nj[q]) w[q] = lz_ld128(src + a[q] + kk); else { w[q].lo = 0; w[q].hi = 0; }
             }
             #pragma unroll
-            for (u32 q = 0; q < 4u; q++) {
+            for (u32 q = 0; q < (u32)PAIRS; q++) {
                 const u32 kk = k + 16u <= nj[q] ? k : nj[q] - 16u;
                 if (k < nj[q]) lz_st128(litOut + o[q] + kk, w[q]);
             }
@@ -327,6 +330,7 @@ LZ_DEV void lz_copy_literal_runs(const u8* src, u8* litOut, u32 mySrc, u32 litAt
 // literal source positions from a prefix sum of literals+match lengths; every lane writes its own
 // escape/offset bytes, then the literal runs of the step are copied 8 sequences at a time (loads of 8
 // runs in flight before the first store).  Trailing literals are appended raw.
+template <int PAIRS>
 LZ_DEV void lz_encode_lz4(const u8* src, u32 S, const LzStreams& st, u8* litOut, u8* flagsOut)
 {
     const u32 lane = lz_lane();
@@ -355,7 +359,7 @@ LZ_DEV void lz_encode_lz4(const u8* src, u32 S, const LzStreams& st, u8* litOut,
             lz_st16_s(r, off);
             for (u32 k = 0; k < extMn; k++) lz_st8_s(r + 2u + k, extMw >> (8u * k));
         }
-        lz_copy_literal_runs(src, litOut, mySrc, myOut + extLn, L);
+        lz_copy_literal_runs<PAIRS>(src, litOut, mySrc, myOut + extLn, L);
         srcPos = lz_readlane(mySrc + adv, 63u);                   // lanes >= cnt hold adv == R == 0
         outPos = lz_readlane(myOut + R, 63u);
     }
@@ -832,7 +836,7 @@ LZ_DEV void lz_pool_release(const LzHufPool& pool, u32 slot)
 // (huffType = LITERALS + FLAGS, lizard_compress.c:374-377) are encoded into the staging areas first (the entropy
 // stage needs them contiguous); the offset streams still go straight to dst.  LIZ: LIZv1 codewords (priceFast),
 // else fastLZ4 codewords (whose off16/off24 streams are always empty).
-template <bool HUF, bool LIZ>
+template <bool HUF, bool LIZ, int PAIRS = 2>
 LZ_DEV u32 lz_write_subblock_seq(const u8* src, u32 S, u32 E, u8* op, LzStreams& st, const LzHufPool& pool)
 {
     const u32 n = E - S, sum = st.nflags + st.nlit + st.noff16 + st.noff24;
@@ -850,11 +854,11 @@ LZ_DEV u32 lz_write_subblock_seq(const u8* src, u32 S, u32 E, u8* op, LzStreams&
             u8* const pl = pf + 3u + st.nflags;
             if (lz_lane() == 0) { lz_st24(pf, st.nflags); lz_st24(pl, st.nlit); }        // :215, :221
             lz_converge();
-            if constexpr (LIZ) lz_encode_lizv1(src, S, st, pl + 3u, pf + 3u, p16 + 3u, p24 + 3u);
-            else               lz_encode_lz4(src, S, st, pl + 3u, pf + 3u);
+            if constexpr (LIZ) lz_encode_lizv1<PAIRS>(src, S, st, pl + 3u, pf + 3u, p16 + 3u, p24 + 3u);
+            else               lz_encode_lz4<PAIRS>(src, S, st, pl + 3u, pf + 3u);
         } else {
-            if constexpr (LIZ) lz_encode_lizv1(src, S, st, st.lit, st.flags, p16 + 3u, p24 + 3u);
-            else               lz_encode_lz4(src, S, st, st.lit, st.flags);
+            if constexpr (LIZ) lz_encode_lizv1<PAIRS>(src, S, st, st.lit, st.flags, p16 + 3u, p24 + 3u);
+            else               lz_encode_lz4<PAIRS>(src, S, st, st.lit, st.flags);
             lz_wave_sync();
             u32 hf = 0, hl = 0, slot;
             u8* q = pf;

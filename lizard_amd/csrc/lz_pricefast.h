@@ -192,6 +192,7 @@ LZ_DEV void lz_seq_sizes_liz(LzStreams& st)
 // Token forms (lizard_decompress_liz.h:1-6): [0_MMMM_LLL] 16-bit offset, [1_MMMM_LLL] repeat offset, 0..31 =
 // 24-bit offset with ml-16 (31 = escape), preceded by a literal-only [1_0000_LLL] when the sequence has literals.
 // Length escapes go to the LITERALS stream (SURVEY finding 4).  Trailing literals are appended raw.
+template <int PAIRS>
 LZ_DEV void lz_encode_lizv1(const u8* src, u32 S, const LzStreams& st, u8* litOut, u8* flagsOut, u8* off16Out, u8* off24Out)
 {
     const u32 lane = lz_lane();
@@ -238,7 +239,7 @@ LZ_DEV void lz_encode_lizv1(const u8* src, u32 S, const LzStreams& st, u8* litOu
             r += extLn + L;
             for (u32 k = 0; k < extMn; k++) r[k] = (u8)(extMw >> (8u * k));
         }
-        lz_copy_literal_runs(src, litOut, mySrc, myOut + extLn, L);
+        lz_copy_literal_runs<PAIRS>(src, litOut, mySrc, myOut + extLn, L);
         srcPos = lz_readlane(mySrc + adv, 63u);                          // lanes >= cnt hold zeros
         outPos = lz_readlane(myOut + R, 63u);
         const u32 pkEnd = lz_readlane(pk + packed, 63u);

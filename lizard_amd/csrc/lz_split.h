@@ -193,7 +193,7 @@ LZ_DEV void lz_split_consumer(const LzSplitArgs& a, const LzSplitShared& sh, u32
         lz_seq_sizes(st);                                                        // the stream sizes the producer did not keep (lz_seq_push<LEAN>)
 #endif
         LZ_PROF(st, 13);                                                         // (profile builds) job header + stream sizes
-        if (E > S) op += lz_write_subblock_seq<HUF, false>(src, S, E, dst + op, st, pool);
+        if (E > S) op += lz_write_subblock_seq<HUF, false, 4>(src, S, E, dst + op, st, pool);
         lz_wave_sync();                                                          // my reads of the list and my staging traffic are done
         if (flags & LZJ_LAST) { if (lane == 0) a.sizes[b] = op; }
         else if (lane == 0) lz_st_shared_u32(opSlot, op);
