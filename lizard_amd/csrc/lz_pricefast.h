@@ -373,6 +373,10 @@ LZ_DEV void lz_parse_pricefast(const u8* src, u32 S, u32 E, const TAB& table, u8
             const u32 hv = lz_readlane(h, f);
             const bool mine = valid && h == hv;
             const u64 g = lz_ballot(mine);
+            // Alone on its slot after all: a false alarm of the tag array (global-memory tables: 64 lanes meet in 2^TAGLOG tag bytes,
+            // about two unrelated pairs per round) — the lane's view and what it leaves behind are already those of a lane alone.
+            // (Round 6: such turns were most of this phase, 10 % of the global-table waves' time.)
+            if ((g & (g - 1ull)) == 0) { pend &= ~g; continue; }
             u32 t = lz_readlane(e, f);
             u32 tc = lz_readlane(ec, f);
             for (u64 m = g; m; m &= m - 1ull) {
