@@ -7,6 +7,7 @@ seed = r*blocks + b)), then (N > 1) the ranks exchange the per-block compressed 
 (inside the library, LizardGPU_gatherSizes_device) so that every rank can compute global output offsets.
 
   python bench.py --gpus 1 --steps 3 --warmup 1
+  python bench.py --gpus N --steps K --warmup W          (no launcher: re-executes itself under torch.distributed.run, one rank per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
@@ -14,7 +15,9 @@ Rank 0 prints ONE JSON line.  Its top-level fields are BASELINE.json configs[1] 
 GPU): `value` = whole-job input MB/s (MB = 10^6 B, as reference programs/bench.c:253-255) over the
 barrier-bracketed timed region of exactly --steps steps, max over ranks.  The same process then times the other
 BASELINE configs with the same --steps / --warmup and reports them under "configs": level 21 and level 30 at
-16 384 x 256 KiB, level 10 at 4 096 x 4 MiB (configs[2..4]); "config1" is configs[0], the reference's own
+16 384 x 256 KiB (configs[2..3]) and configs[4] in BOTH readings: weak scaling — 6 656 x 4 MiB blocks PER GPU, two per
+table-holding wave — and strong scaling — 4 096 x 4 MiB blocks in the WHOLE job (SURVEY 8d read literally), 4 096 / N per GPU, the
+same 4 096 blocks at every N ("scaling": "strong", "blocks_total"); "config1" is configs[0], the reference's own
 CPU-runnable case (64 MiB RDG_genBuffer P50 seed 0 in 256 KiB blocks, programs/bench.c's loop over Lizard_compress).
 Per config:
   roofline      achieved = algorithmic bytes per launch (input read once + compressed output written once,

@@ -11,13 +11,8 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd "$R"; O=gpurun_out/s
 NDEV=$(python -c "import torch; print(torch.cuda.device_count())")
 for N in $NS; do
   if [ "$N" -gt "$NDEV" ]; then echo "N=$N: only $NDEV device(s) visible — skipped (bench.py --transport host-bounce runs the code path on fewer devices, as a functional check)"; continue; fi
-  if [ "$N" = 1 ]; then
-    timeout 1800 python bench.py --gpus 1 --steps $STEPS --warmup $WARMUP --no-cpu "$@" > $O/n$N.json 2> $O/n$N.err
-  else
-    PORT=$((29500 + RANDOM % 2000))
-    timeout 1800 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $PORT \
-        bench.py --gpus $N --steps $STEPS --warmup $WARMUP --no-cpu "$@" > $O/n$N.json 2> $O/n$N.err
-  fi
+  # (python bench.py --gpus N launches its own ranks under torch.distributed.run since round 6 — the driver's form)
+  timeout 1800 python bench.py --gpus $N --steps $STEPS --warmup $WARMUP --no-cpu "$@" > $O/n$N.json 2> $O/n$N.err
   echo "N=$N rc=$?"
 done
 python - "$O" $NS <<'PY'
