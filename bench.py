@@ -87,7 +87,11 @@ def kernel_name(level, bs):
         return "lz_pricefast14_kernel<%s, %s>" % (huf, "true" if bs <= (256 << 10) else "false")
     if base == 22:
         return "lz_pricefast18_kernel<%s>" % huf
-    return "lz_hashchain_kernel<%s, %d>" % (huf, 5 if base <= 15 else 4)
+    if level == 32:
+        return "lz_hashchain_kernel<true, 5, 14>"
+    if level in (12, 33):
+        return "lz_hashchain_kernel<%s, 5, 18>" % huf
+    return "lz_hashchain_kernel<%s, %d, 18>" % (huf, 5 if base <= 15 else 4)
 
 
 def kernel_source_sha16():

@@ -203,8 +203,8 @@ enum {
 };
 
 /* 1 if `compressionLevel` (after the reference's clamp, lib/lizard_compress.c:303-308) runs on the GPU:
- * 10 (fastSmall), 11 (fast), 13..17 (hashChain), 21, 22 (priceFast) and their huff0 twins 30, 31, 34..38, 41, 42 — every
- * row of Lizard_defaultParameters (lib/lizard_common.h:234-284) whose parser is fastSmall, fast, hashChain or priceFast,
+ * 10 (fastSmall), 11 (fast), 12 (noChain), 13..17 (hashChain), 21, 22 (priceFast) and their huff0 twins 30, 31, 32, 33, 34..38,
+ * 41, 42 — every row of Lizard_defaultParameters (lib/lizard_common.h:234-284) whose parser is fastSmall, fast, noChain, hashChain or priceFast,
  * at every block size the reference takes (LIZARD_MAX_INPUT_SIZE, lib/lizard_compress.h:121). */
 int LizardGPU_levelSupported(int compressionLevel);
 /* Largest block (bytes) the GPU path takes at this level: LIZARD_MAX_INPUT_SIZE, or 0 if the level has no GPU kernel. */
@@ -339,7 +339,7 @@ int LizardGPU_arenasInUse(void);
 
 /* Device memory.  A context (one per device) keeps a scratch arena (one slot per resident wave: 2.7 GB on a 256-CU device), and
  * allocates on first use: up to three more arenas for small launches on concurrent streams (released again after 64 launches that
- * did not need them), per-wave tables (levels 21/41: 256 MiB; 11/31/22/42: 4 GiB), hashChain work areas (levels 13-17 / 34-38: up
+ * did not need them), per-wave tables (levels 21/41: 256 MiB; 11/31/22/42: 4 GiB), hashChain work areas (levels 12-17 / 32-38: up
  * to half of the free memory, at most 128 GiB), and the staging of the host-buffer entries (three chunks of 256 MiB in flight).
  * LizardGPU_setMemoryBudget(bytes) bounds the sum per device (0 = no bound, the default): tables and work areas then get fewer
  * slots than there are resident waves (fewer blocks in flight: slower, same bytes), what another level left behind is given up

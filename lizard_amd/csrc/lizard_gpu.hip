@@ -163,7 +163,7 @@ static int ctx_init_body(Ctx& c)
         c.laneOrderOk = bad == 0 && !(force && force[0] == '1');
         if (!c.laneOrderOk)
             fprintf(stderr, "liblizard_amd: device %d: lanes of one LDS atomic are NOT served in lane order (%u violations%s); "
-                            "levels 10, 30, 13-17 and 34-38 are refused on this device\n", c.device, bad, bad ? "" : ", forced by LIZARDGPU_FORCE_LANE_ORDER_FAILURE");
+                            "levels 10, 30, 12-17 and 32-38 are refused on this device\n", c.device, bad, bad ? "" : ", forced by LIZARDGPU_FORCE_LANE_ORDER_FAILURE");
     }
     c.ready = true;
     return 0;
@@ -267,9 +267,12 @@ int clamp_level(int level)                                       // reference li
 // Largest block the GPU path takes at a level (0 = level not on the GPU path).  The table forms of the fast and priceFast
 // parsers keep positions modulo a power of two and sweep (lz_block.h, lz_pricefast.h): any size the reference takes
 // (lib/lizard_compress.h:121).  hashChain keeps full positions; its per-wave work area grows with the block (launch()).
+// hashChain (13-17 / 34-38) and noChain (12 / 32 / 33: the same kernels with one candidate per search, lz_hashchain.h)
+bool hc_level(int lv) { return (lv >= 12 && lv <= 17) || (lv >= 32 && lv <= 38); }
+
 size_t level_max_block(int lv)
 {
-    const bool hcLevel = (lv >= 13 && lv <= 17) || (lv >= 34 && lv <= 38);
+    const bool hcLevel = hc_level(lv);
     if (lv == 10 || lv == 30 || lv == 11 || lv == 31 || lv == 21 || lv == 41 || lv == 22 || lv == 42 || hcLevel) return (size_t)LIZARD_MAX_INPUT_SIZE;
     return 0;
 }
@@ -293,7 +296,7 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
     }
     int rc = ctx_init(c);
     if (rc) return rc;
-    if (!c.laneOrderOk && (lv == 10 || lv == 30 || (lv >= 13 && lv <= 17) || (lv >= 34 && lv <= 38))) {
+    if (!c.laneOrderOk && (lv == 10 || lv == 30 || hc_level(lv))) {
         snprintf(t_err, sizeof t_err, "level %d refused: device %d failed the self-check \"lanes of one LDS atomic are served in lane order\" its kernel relies on", lv, c.device);
         return -LIZARDGPU_ERR_HARDWARE;
     }
@@ -303,7 +306,7 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
     a.scratch = c.scratch; a.counter = c.counter; a.tables = nullptr; a.tableStride = 0; a.tableSlots = 0xFFFFFFFFu;
     a.srcSizes = d_srcSizes; a.srcOffsets = d_srcOffsets; a.activeWaves = 0xFFFFFFFFu;
     // one workgroup of W waves per CU; small batches launch only as many workgroups as they have blocks for
-    const bool hcLevel = (lv >= 13 && lv <= 17) || (lv >= 34 && lv <= 38);
+    const bool hcLevel = hc_level(lv);
     const bool fastMixed = blockSize <= (4u << 20);                         // global-table waves hold 22-bit positions
     const bool pfSmall = blockSize <= (256u << 10);                         // 18-bit LDS tables
     const bool huf = lv >= 30;
@@ -449,9 +452,10 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
 #endif
     case 11: hipLaunchKernelGGL(lz_fast18_kernel<false>, g, t, 0, stream, a); break;
     case 31: hipLaunchKernelGGL(lz_fast18_kernel<true>, g, t, 0, stream, a); break;
-    case 13: case 14: case 15: hipLaunchKernelGGL((lz_hashchain_kernel<false, 5>), g, t, 0, stream, a); break;
+    case 12: case 13: case 14: case 15: hipLaunchKernelGGL((lz_hashchain_kernel<false, 5>), g, t, 0, stream, a); break;
     case 16: case 17:          hipLaunchKernelGGL((lz_hashchain_kernel<false, 4>), g, t, 0, stream, a); break;
-    case 34: case 35: case 36: hipLaunchKernelGGL((lz_hashchain_kernel<true, 5>), g, t, 0, stream, a); break;
+    case 32:                   hipLaunchKernelGGL((lz_hashchain_kernel<true, 5, 14>), g, t, 0, stream, a); break;
+    case 33: case 34: case 35: case 36: hipLaunchKernelGGL((lz_hashchain_kernel<true, 5>), g, t, 0, stream, a); break;
     case 37: case 38:          hipLaunchKernelGGL((lz_hashchain_kernel<true, 4>), g, t, 0, stream, a); break;
     case 22: hipLaunchKernelGGL(lz_pricefast18_kernel<false>, g, t, 0, stream, a); break;
     case 42: hipLaunchKernelGGL(lz_pricefast18_kernel<true>, g, t, 0, stream, a); break;

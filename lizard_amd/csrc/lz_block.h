@@ -926,8 +926,10 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
     LzHc hc;
     if constexpr (PARSER == LZ_PARSER_HASHCHAIN) {
         const u32 row = (level >= 30u ? level - 21u : level) - 13u;                  // lizard_common.h:240-244, :264-268
-        lz_hc_begin(hc, tableMem, maxBlock, row == 4u ? 256u : 2u << row);
-        lz_hc_build<AUX>(src, n, hc, *hcPool, st);
+        const bool noChain = level == 12u || level == 32u || level == 33u;           // :239, :262-263: one candidate per search
+        lz_hc_begin(hc, tableMem, maxBlock, noChain ? 1u : row == 4u ? 256u : 2u << row);
+        hc.noChain = noChain;
+        lz_hc_build<AUX, HASHLOG>(src, n, hc, *hcPool, st);
         // first searches decided ahead of the parse at levels 16/17 / 37/38 (searchLength 4: searchNum 16 / 256, three times the
         // sequences of level 13); at 13-15 the plain hit pass is the faster one (profiles/r04y_*)
         constexpr bool kPre = LZ_HC_PREPASS && AUX == 4;

@@ -1,4 +1,6 @@
-// lz_hashchain.h — hashChain parser (levels 13-17 / 34-38, fastLZ4 codewords) on one wavefront.
+// lz_hashchain.h — hashChain parser (levels 13-17 / 34-38, fastLZ4 codewords) on one wavefront; since round 6 also the noChain
+// parser (levels 12 / 32 / 33, reference lib/lizard_parser_nochain.h), which is the same parse over a chain of length one: see
+// "noChain" below.
 //
 // Bit-exact with reference lib/lizard_parser_hashchain.h (Lizard_Insert :13-43, Lizard_InsertAndFindBestMatch
 // :45-107, Lizard_InsertAndGetWiderMatch :109-185, Lizard_compress_hashChain :188-369) on a zeroed state;
@@ -34,10 +36,18 @@
 //     on ties"; its one-byte pre-checks (:73, :146) are necessary conditions of "strictly longer" and
 //     therefore unobservable.
 //
+//
+// noChain (Lizard_InsertNoChain nochain.h:8-25, Lizard_InsertAndFindBestMatchNoChain :28-80, Lizard_InsertAndGetWiderMatchNoChain
+// :83-143, Lizard_compress_noChain :146-318; parameters lizard_common.h:239, :262-263: windowLog 16, hashLog 18 / 14 / 18, always
+// hash5, nochain.h:4).  Its insert is Lizard_Insert without the chain store (same conditional head update, same MIN_OFFSET), its two
+// searches test ONE candidate — the bucket's head after inserting everything below the position, which is what prev[] records — and
+// its main loop is hashchain.h:188-369 line by line except for one exit the hashChain parser has and noChain has not
+// (hashchain.h:257-260 against nochain.h:210).  So: the chain build of the level's hashLog, searchNum 1, LzHc::noChain.
+//
 // Included from lz_block.h after the shared helpers.
 #pragma once
 
-#define LZ_HC_HASHLOG   18
+#define LZ_HC_HASHLOG   18                      // hashChain levels and noChain levels 12 / 33; level 32: 14 (template parameter HLOG)
 #define LZ_HC_NONE      0x80000000u             // "no head": p - NONE is >= 8 and > 65535 for every block position
 #define LZ_HC_OPTIMAL_ML 18                     // (ML_MASK_LZ4-1)+MINMATCH, hashchain.h:3
 // Chain build geometry (lz_hc_build): a block is handled in segments of 2^18 positions; a segment's positions are split
@@ -45,7 +55,7 @@
 // position order through an LDS window of 2^14 positions.
 #define LZ_HC_SEGLOG    18
 #define LZ_HC_BINLOG    6
-#define LZ_HC_SUBLOG    (LZ_HC_HASHLOG - LZ_HC_BINLOG)
+#define LZ_HC_SUBLOG    (LZ_HC_HASHLOG - LZ_HC_BINLOG)   // slots of a bin's head table (largest form; HLOG 14: 2^8)
 #define LZ_HC_WINLOG    14
 #define LZ_HC_ARENA_WORDS 8192u                 // 32 KiB: head table, then window
 #define LZ_HC_REGION_WORDS (LZ_HC_ARENA_WORDS + 80u)     // + cursors[64] + a spare word
@@ -78,13 +88,14 @@ struct LzHc {
     u32* best;          // global: the first search's result per position (see above)
     u32  searchNum;     // uniform
     bool pre;           // uniform: best[] was filled for this block
+    bool noChain;       // uniform: the noChain parser's arbitration (levels 12 / 32 / 33; searchNum is 1 then)
 };
 
-template <int SEARCHLEN>
+template <int SEARCHLEN, int HLOG>
 LZ_DEV u32 lz_hc_hash(u64 bytes)
 {
-    if constexpr (SEARCHLEN == 4) return ((u32)bytes * 2654435761u) >> (32 - LZ_HC_HASHLOG);     // lizard_compress.c:87-88
-    else return lz_hash5<LZ_HC_HASHLOG>(bytes);                                                   // :90-91
+    if constexpr (SEARCHLEN == 4) return ((u32)bytes * 2654435761u) >> (32 - HLOG);              // lizard_compress.c:87-88
+    else return lz_hash5<HLOG>(bytes);                                                            // :90-91
 }
 
 // Binds a wave's slot (all lanes call).
@@ -101,6 +112,7 @@ LZ_DEV void lz_hc_begin(LzHc& hc, void* slotMem, u32 maxBlock, u32 searchNum)
     hc.best = (u32*)m;
     hc.searchNum = searchNum;
     hc.pre = false;
+    hc.noChain = false;
 }
 
 // Eight source bytes at each of the positions base + 64 k + lane, k = 0..7 (clamped inside the segment; unconditional).
@@ -129,11 +141,12 @@ LZ_DEV lz_u128a4 lz_hc_load_links(const LzHc& hc, u32 lo)
 
 // One step of pass 2: the valid lanes (ascending positions, one bin) read the head of their bucket and become the head —
 // Lizard_Insert's ":38" — through one returning exchange; returns the lane's link (":27-31").  `arena` = the bin's table,
-// slot 2^12 is a spare for the lanes that sit out.
+// slot 2^SUBLOG is a spare for the lanes that sit out.
+template <int SUBLOG>
 LZ_DEV u32 lz_hc_visit(u32* arena, bool valid, u32 hl, u32 p)
 {
     const u32 lane = lz_lane();
-    const u32 old = lz_lds_xchg_rtn(arena + (valid ? hl : (1u << LZ_HC_SUBLOG)), p);
+    const u32 old = lz_lds_xchg_rtn(arena + (valid ? hl : (1u << SUBLOG)), p);
     u32 seen = old;                                              // head as my own insertion sees it
     u64 pend = lz_ballot(valid && p - old < LZ_MIN_OFFSET);
     if (pend) {                                                  // ":38" did not happen for some lane: replay its bucket in order
@@ -173,9 +186,11 @@ LZ_DEV u32 lz_hc_visit(u32* arena, bool valid, u32 hl, u32 p)
 //           LDS window at their position; the window leaves as prev[], coalesced.
 // Blocks above 2^18 positions run segment after segment; the head tables travel through `heads` in between.
 // The LDS region (32.3 KiB) is borrowed from the workgroup's pool for the duration of the build.
-template <int SEARCHLEN>
+template <int SEARCHLEN, int HLOG>
 LZ_DEV void lz_hc_build(const u8* src, u32 n, const LzHc& hc, const LzHufPool& pool, LzStreams& st)
 {
+    static_assert(HLOG > LZ_HC_BINLOG && HLOG <= LZ_HC_HASHLOG, "64 bins of 2^(HLOG - 6) slots; the areas are sized for 2^18");
+    constexpr int kSubLog = HLOG - LZ_HC_BINLOG;
     const u32 lane = lz_lane();
     const u32 nIns = n >= 8u ? n - 7u : 0u;
     if (!nIns) return;
@@ -184,7 +199,7 @@ LZ_DEV void lz_hc_build(const u8* src, u32 n, const LzHc& hc, const LzHufPool& p
     LZ_PROF(st, 7);                                              // (instrumented build) waiting for a region
     u32* const cur = arena + LZ_HC_ARENA_WORDS;                  // [0..63] cursors, [64] spare
     u16* const win16 = (u16*)arena;
-    constexpr u32 kSeg = 1u << LZ_HC_SEGLOG, kSub = 1u << LZ_HC_SUBLOG, kWin = 1u << LZ_HC_WINLOG;
+    constexpr u32 kSeg = 1u << LZ_HC_SEGLOG, kSub = 1u << kSubLog, kWin = 1u << LZ_HC_WINLOG;
     for (u32 seg = 0; seg < nIns; seg += kSeg) {
         const u32 segLen = (nIns - seg) < kSeg ? (nIns - seg) : kSeg;
         const bool firstSeg = seg == 0u, lastSeg = seg + segLen >= nIns;
@@ -202,8 +217,8 @@ LZ_DEV void lz_hc_build(const u8* src, u32 n, const LzHc& hc, const LzHufPool& p
                 #pragma unroll
                 for (u32 k = 0; k < LZ_HC_GRP; k++) {
                     const u32 p = base + k * 64u + lane;
-                    const u32 h = lz_hc_hash<SEARCHLEN>(x[k]);
-                    lz_lds_atomic_add(cur + (p < segLen ? h >> LZ_HC_SUBLOG : 64u), 1u);
+                    const u32 h = lz_hc_hash<SEARCHLEN, HLOG>(x[k]);
+                    lz_lds_atomic_add(cur + (p < segLen ? h >> kSubLog : 64u), 1u);
                     x[k] = y[k];
                 }
             }
@@ -229,8 +244,8 @@ LZ_DEV void lz_hc_build(const u8* src, u32 n, const LzHc& hc, const LzHufPool& p
                         if (base && !(base & (kWin - 1u))) hc.wins[(base >> LZ_HC_WINLOG) * 64u + lane] = cur[lane];
                         const u32 p = base + lane;
                         const bool valid = p < segLen;
-                        const u32 h = lz_hc_hash<SEARCHLEN>(x[k]);
-                        const u32 bin = valid ? h >> LZ_HC_SUBLOG : 64u;
+                        const u32 h = lz_hc_hash<SEARCHLEN, HLOG>(x[k]);
+                        const u32 bin = valid ? h >> kSubLog : 64u;
                         const u32 s = lz_lds_add_rtn(cur + bin, 1u);
                         if (valid) hc.bins[s] = ((h & (kSub - 1u)) << LZ_HC_SEGLOG) | p;    // a bin's line fills within ~32 steps: merged in L2
                     }
@@ -262,7 +277,7 @@ LZ_DEV void lz_hc_build(const u8* src, u32 n, const LzHc& hc, const LzHufPool& p
                 const u32 hl = e0 >> LZ_HC_SEGLOG, p = seg + (e0 & (kSeg - 1u));
                 u32 link;
                 if (!fresh && bEnd >= stepEnd)                       // the whole step lies in the current bin: straight-line code
-                    link = lz_hc_visit(arena, idx < stepEnd, hl, p);
+                    link = lz_hc_visit<kSubLog>(arena, idx < stepEnd, hl, p);
                 else {
                     u32 from = j * 64u;                              // first entry of this step not served yet (uniform)
                     link = 0;
@@ -285,7 +300,7 @@ LZ_DEV void lz_hc_build(const u8* src, u32 n, const LzHc& hc, const LzHufPool& p
                         }
                         const u32 to = bEnd < stepEnd ? bEnd : stepEnd;
                         const bool valid = idx >= from && idx < to;
-                        const u32 l = lz_hc_visit(arena, valid, hl, p);
+                        const u32 l = lz_hc_visit<kSubLog>(arena, valid, hl, p);
                         if (valid) link = l;
                         from = to;
                     }
@@ -698,7 +713,7 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const Lz
             if (new_ml > LZ_HC_OPTIMAL_ML) new_ml = LZ_HC_OPTIMAL_ML;
             if (ip + new_ml > (int)start2 + ml2 - 4) {
                 new_ml = (int)start2 - ip + ml2 - 4;
-                if (new_ml < 4) {
+                if (new_ml < 4 && !hc.noChain) {                                                  // hashchain.h:257-260; nochain.h:210 has no such exit
                     lz_seq_push(st, (u32)(ip - anchor), (u32)ml, (u32)ip - ref); ip += ml; anchor = ip;
                     continue;
                 }

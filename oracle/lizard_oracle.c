@@ -29,7 +29,7 @@
 #define LZO_FLAG_LEN          16
 #define LZO_FLAG_UNCOMPRESSED 128
 
-typedef enum { P_FAST, P_PRICEFAST, P_HASHCHAIN } lzo_parser;
+typedef enum { P_FAST, P_PRICEFAST, P_HASHCHAIN, P_NOCHAIN } lzo_parser;
 typedef enum { C_LZ4, C_LIZV1 } lzo_codewords;
 
 typedef struct {
@@ -47,7 +47,12 @@ static int lzo_get_params(int level, lzo_params* p)
     p->huffman = level >= 30;
     p->contentLog = 0; p->searchNum = 0; p->searchLength = 5;
     if (level >= 34 && level <= 38) base = level - 21;          /* 34..38 repeat the rows of 13..17 (lizard_common.h:264-268) */
-    else if (level == 32 || level == 33 || level == 39 || level == 12 || level == 18 || level == 19) return 0;
+    else if (level == 39 || level == 18 || level == 19) return 0;
+    /* noChain, LZ4 codewords: lizard_common.h:239 (12), :262-263 (32: hashLog 14, 33: hashLog 18) */
+    if (level == 12 || level == 32 || level == 33) {
+        p->windowLog = 16; p->hashLog = level == 32 ? 14 : 18; p->minMatchLongOff = 0; p->searchNum = 1;
+        p->parser = P_NOCHAIN; p->codewords = C_LZ4; return 1;
+    }
     switch (base) {
     case 10: p->windowLog = 16; p->hashLog = 12; p->minMatchLongOff = 0;  p->parser = P_FAST;      p->codewords = C_LZ4;   return 1;
     case 11: p->windowLog = 16; p->hashLog = 18; p->minMatchLongOff = 0;  p->parser = P_FAST;      p->codewords = C_LZ4;   return 1;
@@ -409,9 +414,77 @@ static int hc_wider(lzo_ctx* c, uint32_t ip, uint32_t iLow, uint32_t iHigh, int 
     return longest;
 }
 
-/* Lizard_compress_hashChain, hashchain.h:188-369 (LZ4HC-style three-match lazy arbitration). */
+/* ---- noChain parser (levels 12 / 32 / 33): reference lib/lizard_parser_nochain.h -------------------
+ * The hashChain parser without a chain: one candidate per search (the bucket's head), hash5 whatever the level's
+ * searchLength (nochain.h:4), the same conditional head update. */
+/* Lizard_InsertNoChain, nochain.h:8-25 */
+static void nc_insert(lzo_ctx* c, uint32_t target)
+{
+    uint32_t pos = c->nextToUpdate;
+    while (pos < target) {
+        const uint32_t idx = pos + LZO_DICT_SIZE, h = hash5(c->src + pos, c->prm.hashLog), head = c->table[h];
+        if (head >= idx || idx >= head + LZO_MIN_OFFSET) c->table[h] = idx;
+        pos++;
+    }
+    c->nextToUpdate = target;
+}
+
+/* Lizard_InsertAndFindBestMatchNoChain, nochain.h:28-80 */
+static int nc_find_best(lzo_ctx* c, uint32_t ip, uint32_t iLimit, uint32_t* ref)
+{
+    const uint8_t* src = c->src;
+    const uint32_t maxDist = (1u << c->prm.windowLog) - 1, cur = ip + LZO_DICT_SIZE;
+    const uint32_t lowLimit = (LZO_DICT_SIZE + maxDist >= cur) ? LZO_DICT_SIZE : cur - maxDist;
+    uint32_t ml = 0, mi;
+    nc_insert(c, ip);
+    mi = c->table[hash5(src + ip, c->prm.hashLog)];
+    if (mi < cur && mi >= lowLimit) {
+        const uint32_t m = mi - LZO_DICT_SIZE;
+        if (ip - m >= LZO_MIN_OFFSET && src[m] == src[ip] && rd32(src + m) == rd32(src + ip)) {
+            ml = LZO_MINMATCH + count_eq(src, ip + 4, m + 4, iLimit);
+            *ref = m;
+        }
+    }
+    return (int)ml;
+}
+
+/* Lizard_InsertAndGetWiderMatchNoChain, nochain.h:83-143 */
+static int nc_wider(lzo_ctx* c, uint32_t ip, uint32_t iLow, uint32_t iHigh, int longest, uint32_t* ref, uint32_t* start)
+{
+    const uint8_t* src = c->src;
+    const uint32_t maxDist = (1u << c->prm.windowLog) - 1, cur = ip + LZO_DICT_SIZE;
+    const uint32_t lowLimit = (LZO_DICT_SIZE + maxDist >= cur) ? LZO_DICT_SIZE : cur - maxDist;
+    const int LLdelta = (int)(ip - iLow);
+    uint32_t mi;
+    nc_insert(c, ip);
+    mi = c->table[hash5(src + ip, c->prm.hashLog)];
+    if (mi < cur && mi >= lowLimit) {
+        const uint32_t m = mi - LZO_DICT_SIZE;
+        if (ip - m >= LZO_MIN_OFFSET && src[iLow + longest] == src[m - LLdelta + longest] && rd32(src + m) == rd32(src + ip)) {
+            int mlt = LZO_MINMATCH + (int)count_eq(src, ip + 4, m + 4, iHigh), back = 0;
+            while (ip + back > iLow && m + back > 0 && src[ip + back - 1] == src[m + back - 1]) back--;
+            mlt -= back;
+            if (mlt > longest) { longest = mlt; *ref = m + back; *start = ip + back; }
+        }
+    }
+    return longest;
+}
+
+static int find_best(lzo_ctx* c, uint32_t ip, uint32_t iLimit, uint32_t* ref)
+{
+    return c->prm.parser == P_NOCHAIN ? nc_find_best(c, ip, iLimit, ref) : hc_find_best(c, ip, iLimit, ref);
+}
+static int wider(lzo_ctx* c, uint32_t ip, uint32_t iLow, uint32_t iHigh, int longest, uint32_t* ref, uint32_t* start)
+{
+    return c->prm.parser == P_NOCHAIN ? nc_wider(c, ip, iLow, iHigh, longest, ref, start) : hc_wider(c, ip, iLow, iHigh, longest, ref, start);
+}
+
+/* Lizard_compress_hashChain, hashchain.h:188-369 (LZ4HC-style three-match lazy arbitration), and Lizard_compress_noChain,
+ * nochain.h:146-318: the same loop over the searches above, except that noChain has no "match2 does not fit" exit in the first
+ * shortening step (nochain.h:210 against hashchain.h:255-261). */
 static void parse_hashchain(lzo_ctx* c, uint32_t S, uint32_t E)
 {
+    const int nochain = c->prm.parser == P_NOCHAIN;
     int anchor = (int)S, ip = (int)S, mflimit, matchlimit;
     int ml, ml2, ml3, ml0;
     uint32_t ref = 0, ref2 = 0, ref3 = 0, ref0, start2 = 0, start3 = 0;
@@ -420,11 +493,11 @@ static void parse_hashchain(lzo_ctx* c, uint32_t S, uint32_t E)
     mflimit = (int)E - (int)LZO_MFLIMIT; matchlimit = (int)E - (int)LZO_LASTLITERALS;
     ip++;
     while (ip < mflimit) {
-        ml = hc_find_best(c, (uint32_t)ip, (uint32_t)matchlimit, &ref);
+        ml = find_best(c, (uint32_t)ip, (uint32_t)matchlimit, &ref);
         if (!ml) { ip++; continue; }
         start0 = ip; ref0 = ref; ml0 = ml;
     search2:
-        if (ip + ml < mflimit) ml2 = hc_wider(c, (uint32_t)(ip + ml - 2), (uint32_t)(ip + 1), (uint32_t)matchlimit, ml, &ref2, &start2);
+        if (ip + ml < mflimit) ml2 = wider(c, (uint32_t)(ip + ml - 2), (uint32_t)(ip + 1), (uint32_t)matchlimit, ml, &ref2, &start2);
         else ml2 = ml;
         if (ml2 == ml) {                                                          /* :216-219 */
             emit_seq(c, (uint32_t)anchor, (uint32_t)ip, (uint32_t)ml, ref); ip += ml; anchor = ip;
@@ -443,7 +516,7 @@ static void parse_hashchain(lzo_ctx* c, uint32_t S, uint32_t E)
             if (new_ml > HC_OPTIMAL_ML) new_ml = HC_OPTIMAL_ML;
             if (ip + new_ml > (int)start2 + ml2 - LZO_MINMATCH) {
                 new_ml = (int)start2 - ip + ml2 - LZO_MINMATCH;
-                if (new_ml < LZO_MINMATCH) {
+                if (!nochain && new_ml < LZO_MINMATCH) {                           /* hashchain.h:257-260 only */
                     emit_seq(c, (uint32_t)anchor, (uint32_t)ip, (uint32_t)ml, ref); ip += ml; anchor = ip;
                     continue;
                 }
@@ -452,7 +525,7 @@ static void parse_hashchain(lzo_ctx* c, uint32_t S, uint32_t E)
             if (correction > 0) { start2 += (uint32_t)correction; ref2 += (uint32_t)correction; ml2 -= correction; }
         }
         if ((int)start2 + ml2 < mflimit)                                          /* :263-265 */
-            ml3 = hc_wider(c, start2 + (uint32_t)ml2 - 3, start2, (uint32_t)matchlimit, ml2, &ref3, &start3);
+            ml3 = wider(c, start2 + (uint32_t)ml2 - 3, start2, (uint32_t)matchlimit, ml2, &ref3, &start3);
         else ml3 = ml2;
         if (ml3 == ml2) {                                                         /* :267-275 */
             if ((int)start2 < ip + ml) ml = (int)start2 - ip;
@@ -602,7 +675,7 @@ int lzo_compress(const void* srcv, void* dstv, int srcSize, int dstCapacity, int
         if (part > LZO_SUBBLOCK) part = LZO_SUBBLOCK;
         c.nlit = c.nflags = c.noff16 = c.noff24 = 0; c.last_off = 0;              /* Lizard_initBlock :130-138 */
         if (c.prm.parser == P_FAST) parse_fast(&c, pos, pos + part);
-        else if (c.prm.parser == P_HASHCHAIN) parse_hashchain(&c, pos, pos + part);
+        else if (c.prm.parser == P_HASHCHAIN || c.prm.parser == P_NOCHAIN) parse_hashchain(&c, pos, pos + part);
         else parse_pricefast(&c, pos, pos + part);
         if (write_block(&c, src + pos, part, &op, oend, hufTmp, hufTmpCap)) goto done;   /* :535 */
         pos += part;

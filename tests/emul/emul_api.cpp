@@ -47,8 +47,9 @@ extern "C" int emul_compress_block(const void* src, int n, void* dst, int level,
     Args a;
     int base = level >= 30 ? level - 20 : level;
     if (level >= 34 && level <= 38) base = level - 21;
-    const bool hcLevel = base >= 13 && base <= 17;
-    int hashLog = base == 10 ? 12 : base == 11 ? 18 : base == 21 ? 14 : base == 22 ? 18 : hcLevel ? 18 : 0;
+    const bool ncLevel = level == 12 || level == 32 || level == 33;       // noChain: the hashChain kernels with one candidate per search
+    const bool hcLevel = (base >= 13 && base <= 17) || ncLevel;
+    int hashLog = ncLevel ? (level == 32 ? 14 : 18) : base == 10 ? 12 : base == 11 ? 18 : base == 21 ? 14 : base == 22 ? 18 : hcLevel ? 18 : 0;
     if (!hashLog) return -1;
     if (hcLevel && (size_t)n > kHcMaxBlock) return -1;
     a.src = (const u8*)src; a.n = (u32)n; a.dst = (u8*)dst; a.level = (u32)level; a.result = 0;
@@ -72,7 +73,9 @@ extern "C" int emul_compress_block(const void* src, int n, void* dst, int level,
     if (a.wideOcc) memset(a.wideOcc, 0x77, 8192 + 8);
     a.hcRegion = (u32*)aligned_alloc(64, 4 * LZ_HC_REGION_WORDS + 64);
     memset(a.hcRegion, 0x3C, 4 * LZ_HC_REGION_WORDS);
-    switch (base) {
+    if (level == 32) lzemu::run_wave(entry_block<LZ_PARSER_HASHCHAIN, 14, 5, true>, &a, seed);
+    else if (ncLevel) lzemu::run_wave(huf ? entry_block<LZ_PARSER_HASHCHAIN, 18, 5, true> : entry_block<LZ_PARSER_HASHCHAIN, 18, 5, false>, &a, seed);
+    else switch (base) {
     case 13: case 14: case 15: lzemu::run_wave(huf ? entry_block<LZ_PARSER_HASHCHAIN, 18, 5, true> : entry_block<LZ_PARSER_HASHCHAIN, 18, 5, false>, &a, seed); break;
     case 16: case 17:          lzemu::run_wave(huf ? entry_block<LZ_PARSER_HASHCHAIN, 18, 4, true> : entry_block<LZ_PARSER_HASHCHAIN, 18, 4, false>, &a, seed); break;
     case 10: lzemu::run_wave(huf ? entry_block<LZ_PARSER_FAST, 12, 0, true> : entry_block<LZ_PARSER_FAST, 12, 0, false>, &a, seed); break;

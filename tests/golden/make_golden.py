@@ -2,7 +2,8 @@
 /root/reference (oracle/_ref/liblizard_ref_reset.so, i.e. -DLIZARD_RESET_MEM: zero-initialised state).
 
 Run in the build container (the reference does not exist on the GPU box):
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py                  (everything; --add-known-answers / --add-levels keep what is recorded and add
+                                                         the missing 64 MiB known answers / the levels the cases do not have yet)
 Inputs are regenerated deterministically by tests/util.corpus(); the JSON pins sha256(input) too, so a
 drift of the generator restatement is detected rather than silently re-blessed.
 """
@@ -15,10 +16,11 @@ import xxhash
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import util  # noqa: E402
 
-LEVELS = [10, 11, 13, 14, 15, 16, 17, 21, 22, 30, 31, 34, 35, 36, 37, 38, 41, 42]
+LEVELS = [10, 11, 12, 13, 14, 15, 16, 17, 21, 22, 30, 31, 32, 33, 34, 35, 36, 37, 38, 41, 42]
 P50_64M_KEYS = [(10, 262144), (11, 262144), (21, 262144), (30, 262144), (10, 4 << 20), (10, 65536), (13, 262144), (15, 262144),
                 (17, 262144), (35, 262144), (22, 262144), (31, 262144), (41, 262144), (42, 262144),
-                (14, 262144), (16, 262144), (34, 262144), (36, 262144), (37, 262144), (38, 262144)]
+                (14, 262144), (16, 262144), (34, 262144), (36, 262144), (37, 262144), (38, 262144),
+                (12, 262144), (32, 262144), (33, 262144)]
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_vectors.json")
 
 
@@ -28,12 +30,19 @@ def main():
     dg = util.reference_datagen()
     vec = {"levels": LEVELS, "cases": {}, "frame_style": {}, "p50_64m": {}}
     add_only = "--add-known-answers" in sys.argv          # keep everything recorded, add the missing 64 MiB known answers
-    if add_only:
+    add_levels = "--add-levels" in sys.argv               # keep everything recorded, add the levels of LEVELS the cases do not have yet
+    if add_only or add_levels:
         with open(OUT) as f:
             vec = json.load(f)
+        vec["levels"] = LEVELS
     for name, data in ([] if add_only else util.corpus() + util.corpus_long()):
         entry = {"n": len(data), "input_sha256": util.sha(data), "out": {}}
+        if add_levels:
+            entry = vec["cases"][name]
+            assert entry["n"] == len(data) and entry["input_sha256"] == util.sha(data), name
         for lvl in LEVELS:
+            if str(lvl) in entry["out"]:
+                continue
             out, r = util.compress_with(ref.Lizard_compress, data, lvl)
             entry["out"][str(lvl)] = {"size": r, "sha256": util.sha(out)}
         # frame-style capacity (lizard_frame.c:461: maxDstSize = srcSize-1): 0 when it does not fit
