@@ -83,6 +83,8 @@ def kernel_name(level, bs):
         return "lz_fast12_split_kernel<%s>" % huf
     if base == 11:
         return "lz_fast18_kernel<%s>" % huf
+    if base == 20:
+        return "lz_fastbig14_kernel<%s>" % huf
     if base == 21:
         return "lz_pricefast14_kernel<%s, %s>" % (huf, "true" if bs <= (256 << 10) else "false")
     if base == 22:

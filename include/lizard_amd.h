@@ -203,8 +203,9 @@ enum {
 };
 
 /* 1 if `compressionLevel` (after the reference's clamp, lib/lizard_compress.c:303-308) runs on the GPU:
- * 10 (fastSmall), 11 (fast), 12 (noChain), 13..17 (hashChain), 21, 22 (priceFast) and their huff0 twins 30, 31, 32, 33, 34..38,
- * 41, 42 — every row of Lizard_defaultParameters (lib/lizard_common.h:234-284) whose parser is fastSmall, fast, noChain, hashChain or priceFast,
+ * 10 (fastSmall), 11 (fast), 12 (noChain), 13..17 (hashChain), 20 (fastBig), 21, 22 (priceFast) and their huff0 twins 30, 31, 32, 33,
+ * 34..38, 40, 41, 42 — every row of Lizard_defaultParameters (lib/lizard_common.h:234-284) whose parser is fastSmall, fast, noChain, hashChain,
+ * fastBig or priceFast (23 of the 40 levels; the others are the price-based parsers),
  * at every block size the reference takes (LIZARD_MAX_INPUT_SIZE, lib/lizard_compress.h:121). */
 int LizardGPU_levelSupported(int compressionLevel);
 /* Largest block (bytes) the GPU path takes at this level: LIZARD_MAX_INPUT_SIZE, or 0 if the level has no GPU kernel. */

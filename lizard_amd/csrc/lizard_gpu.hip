@@ -273,7 +273,7 @@ bool hc_level(int lv) { return (lv >= 12 && lv <= 17) || (lv >= 32 && lv <= 38);
 size_t level_max_block(int lv)
 {
     const bool hcLevel = hc_level(lv);
-    if (lv == 10 || lv == 30 || lv == 11 || lv == 31 || lv == 21 || lv == 41 || lv == 22 || lv == 42 || hcLevel) return (size_t)LIZARD_MAX_INPUT_SIZE;
+    if (lv == 10 || lv == 30 || lv == 11 || lv == 31 || lv == 20 || lv == 40 || lv == 21 || lv == 41 || lv == 22 || lv == 42 || hcLevel) return (size_t)LIZARD_MAX_INPUT_SIZE;
     return 0;
 }
 
@@ -457,6 +457,8 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
     case 32:                   hipLaunchKernelGGL((lz_hashchain_kernel<true, 5, 14>), g, t, 0, stream, a); break;
     case 33: case 34: case 35: case 36: hipLaunchKernelGGL((lz_hashchain_kernel<true, 5>), g, t, 0, stream, a); break;
     case 37: case 38:          hipLaunchKernelGGL((lz_hashchain_kernel<true, 4>), g, t, 0, stream, a); break;
+    case 20: hipLaunchKernelGGL(lz_fastbig14_kernel<false>, g, t, 0, stream, a); break;
+    case 40: hipLaunchKernelGGL(lz_fastbig14_kernel<true>, g, t, 0, stream, a); break;
     case 22: hipLaunchKernelGGL(lz_pricefast18_kernel<false>, g, t, 0, stream, a); break;
     case 42: hipLaunchKernelGGL(lz_pricefast18_kernel<true>, g, t, 0, stream, a); break;
     case 21: if (pfSmall) hipLaunchKernelGGL((lz_pricefast14_kernel<false, true>), g, t, 0, stream, a);

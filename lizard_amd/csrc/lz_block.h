@@ -798,6 +798,7 @@ tail:
 LZ_DEV void lz_st24(u8* p, u32 v) { p[0] = (u8)v; p[1] = (u8)(v >> 8); p[2] = (u8)(v >> 16); }
 
 #include "lz_pricefast.h"   // priceFast parser + LIZv1 encoder (uses the helpers above)
+#include "lz_fastbig.h"     // fastBig parser (levels 20 / 40): the fast parser's rounds over a 4 MiB window, LIZv1 sequence list
 // LDS pools of a workgroup (Huffman workspaces; chain-build regions of the hashChain levels).  A wave needs its LZ_HUF_WS_WORDS of LDS only while it entropy-codes a sub-block
 // (about a third of its time at level 30), so the W waves of a workgroup share K < W workspaces and the LDS this frees
 // holds more hash tables.  A wave holding a workspace never waits for anything else: no deadlock; waves that find the pool
@@ -893,10 +894,12 @@ LZ_DEV u32 lz_write_subblock_seq(const u8* src, u32 S, u32 E, u8* op, LzStreams&
 //   LZ_TABKIND_LDS18   priceFast only: LZ_TAB24C_BYTES(HASHLOG) bytes of LDS, 18-bit position + 6 check bits (LzTab24c, blocks <= 256 KiB)
 // AUX:      priceFast -> TAGLOG of the round tag array (ws holds 2^TAGLOG bytes of LDS).
 //           hashChain -> searchLength (4 or 5); tableMem = the wave's LZ_HC_SLOT_BYTES slot (global; nothing in it needs clearing).
-// PARSER: 0 = fastSmall/fast + fastLZ4 codewords, 1 = priceFast + LIZv1 codewords, 2 = hashChain + fastLZ4 codewords.
+// PARSER: 0 = fastSmall/fast + fastLZ4 codewords, 1 = priceFast + LIZv1 codewords, 2 = hashChain / noChain + fastLZ4 codewords,
+//         3 = fastBig + LIZv1 codewords (AUX = TAGLOG; the table is the wave's global-memory slot of 4 << HASHLOG bytes, LzTab32G).
 #define LZ_PARSER_FAST      0
 #define LZ_PARSER_PRICEFAST 1
 #define LZ_PARSER_HASHCHAIN 2
+#define LZ_PARSER_FASTBIG   3
 #define LZ_TABKIND_LDS      0u
 #define LZ_TABKIND_GLOBAL   1u
 #define LZ_TABKIND_LDS18    2u
@@ -907,7 +910,7 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
 {
     const u32 lane = lz_lane();
     LzStreams st;
-    constexpr bool kLiz = PARSER == LZ_PARSER_PRICEFAST;                                   // LIZv1 codewords
+    constexpr bool kLiz = PARSER == LZ_PARSER_PRICEFAST || PARSER == LZ_PARSER_FASTBIG;    // LIZv1 codewords
     lz_streams_bind(st, scratch, !kLiz, seqRing);
 #ifdef LZ_PROFILE
     st.prof_last = __builtin_readcyclecounter();
@@ -936,6 +939,7 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
         hc.pre = kPre;
         if constexpr (kPre) lz_hc_hits(src, n, hc); else lz_hc_hits_plain(src, n, hc);
     }
+    else if constexpr (PARSER == LZ_PARSER_FASTBIG) { lz_pf_tab_fresh<HASHLOG>(pf32g); st.sweepAt = LZ_PF_SWEEP_EVERY; }
     else if constexpr (kWide) { lz_tab_fresh<HASHLOG>(tabw); st.sweepAt = LzTabWide::kSweepEvery; }
     else if constexpr (PARSER == LZ_PARSER_FAST) {
         if (tabKind == LZ_TABKIND_GLOBAL) { lz_tab_fresh<HASHLOG>(tabw); st.sweepAt = LzTabWide::kSweepEvery; }
@@ -954,6 +958,7 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
         st.nlit = st.nflags = st.noff16 = st.noff24 = 0;      // Lizard_initBlock, :130-138
         st.nseq = 0; st.lastLits = 0;
         if constexpr (PARSER == LZ_PARSER_HASHCHAIN) lz_parse_hashchain(src, n, pos, pos + part, hc, st);
+        else if constexpr (PARSER == LZ_PARSER_FASTBIG) lz_parse_fastbig<HASHLOG, AUX>(src, pos, pos + part, pf32g, ws, st);
         else if constexpr (kWide)                    lz_parse_fast<HASHLOG>(src, pos, pos + part, tabw, st);
         else if constexpr (PARSER == LZ_PARSER_FAST) {
             if (tabKind == LZ_TABKIND_GLOBAL) lz_parse_fast<HASHLOG>(src, pos, pos + part, tabw, st);

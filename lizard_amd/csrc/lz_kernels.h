@@ -208,6 +208,15 @@ __global__ __launch_bounds__(64 * LZ_WAVES_HC) void lz_hashchain_kernel(LzBatch 
     lz_wave_main<LZ_PARSER_HASHCHAIN, HLOG, SEARCHLEN, HUF, LZ_WAVES_HC, (HUF ? LZ_HUF_WS_WORDS : 1), 0>(a);
 }
 
+// levels 20 / 40: fastBig + LIZv1 (lz_fastbig.h), 2^14 u32 slots per wave in its global-memory slot (the slots of levels 21 / 41),
+// tag array of the rounds in LDS (with Huffman: the 2 KiB workspace doubles as it)
+#define LZ_WAVES_FASTBIG 16
+template <bool HUF>
+__global__ __launch_bounds__(64 * LZ_WAVES_FASTBIG) void lz_fastbig14_kernel(LzBatch a)
+{
+    lz_wave_main<LZ_PARSER_FASTBIG, 14, (HUF ? 11 : 10), HUF, LZ_WAVES_FASTBIG, (HUF ? LZ_HUF_WS_WORDS : (1u << 10) / 4u), 0>(a);
+}
+
 // levels 21 / 41: priceFast + LIZv1, 2^14-slot table.  A wave whose table is in LDS is bound by the issue latency of its own
 // instruction chain (one exposed memory trip per sequence, lz_pricefast.h); the waves beyond the LDS's three tables keep the
 // table in a global-memory slot (every probe a 128-byte line) and fill the issue slots the LDS waves leave.  Two forms by block size:

@@ -62,6 +62,8 @@ static int lzo_get_params(int level, lzo_params* p)
         p->windowLog = 16; p->hashLog = 18; p->minMatchLongOff = 0; p->contentLog = 16;
         p->searchNum = snum[base - 13]; p->searchLength = slen[base - 13];
         p->parser = P_HASHCHAIN; p->codewords = C_LZ4; return 1; }
+    /* fastBig, LIZv1 codewords: lizard_common.h:248 (20) and :270 (40) */
+    case 20: p->windowLog = 22; p->hashLog = 14; p->minMatchLongOff = 16; p->parser = P_FAST;      p->codewords = C_LIZV1; return 1;
     case 21: p->windowLog = 22; p->hashLog = 14; p->minMatchLongOff = 16; p->parser = P_PRICEFAST; p->codewords = C_LIZV1; return 1;
     case 22: p->windowLog = 22; p->hashLog = 18; p->minMatchLongOff = 16; p->parser = P_PRICEFAST; p->codewords = C_LIZV1; return 1;
     default: return 0;
@@ -180,11 +182,15 @@ static void emit_last_literals(lzo_ctx* c, uint32_t anchor, uint32_t end)
     memcpy(c->lit + c->nlit, c->src + anchor, end - anchor); c->nlit += end - anchor;
 }
 
-/* ---- fastSmall / fast parser: reference lib/lizard_parser_fastsmall.h:34-189 == lizard_parser_fast.h:41-196 */
+/* ---- fastSmall / fast parser: reference lib/lizard_parser_fastsmall.h:34-189 == lizard_parser_fast.h:41-196,
+ * and fastBig (levels 20 / 40): lib/lizard_parser_fastbig.h:36-175 — the same loop with the level's hashLog and window, LIZv1
+ * codewords (:127), and the long-offset rule: a candidate 65 536 or more back counts only when the forward count behind the first
+ * four bytes plus the backward extension is at least minMatchLongOff (:92-98 in the search, :143-146 in the post-match probe). */
 static void parse_fast(lzo_ctx* c, uint32_t S, uint32_t E)
 {
     const uint8_t* src = c->src;
     const unsigned hl = c->prm.hashLog;
+    const uint32_t mmlo = c->prm.minMatchLongOff;   /* 0: fast / fastSmall (LIZARD_FAST_LONGOFF_MM 0, fast.h:2) */
     const uint32_t maxDist = (1u << c->prm.windowLog) - 1;
     /* fast.h:57-58: lowLimit fixed at sub-block entry; ctx->lowLimit = dictLimit = 2^24 for a fresh block */
     const uint32_t idxS = S + LZO_DICT_SIZE;
@@ -213,7 +219,12 @@ static void parse_fast(lzo_ctx* c, uint32_t S, uint32_t E)
                 if (ip - match < LZO_MIN_OFFSET) continue;                        /* fast.h:95 */
                 if (rd32(src + match) != rd32(src + ip)) continue;                /* fast.h:97 */
                 ml = LZO_MINMATCH + count_eq(src, ip + 4, match + 4, matchlimit); /* fast.h:100 */
-                while (ip > anchor && match > 0 && src[ip - 1] == src[match - 1]) { ip--; match--; ml++; }  /* :102-103 */
+                {
+                    uint32_t bk = 0;                                              /* fast.h:102-103 / fastbig.h:94-100 */
+                    while (ip - bk > anchor && match - bk > 0 && src[ip - bk - 1] == src[match - bk - 1]) bk++;
+                    if (mmlo && !(ml - LZO_MINMATCH + bk >= mmlo || ip - match < LZO_16BIT_OFFSET)) continue;   /* fastbig.h:96 */
+                    ip -= bk; match -= bk; ml += bk;
+                }
                 break;
             }
             for (;;) {
@@ -230,6 +241,7 @@ static void parse_fast(lzo_ctx* c, uint32_t S, uint32_t E)
                     match = e - LZO_DICT_SIZE;
                     if (ip - match >= LZO_MIN_OFFSET && rd32(src + match) == rd32(src + ip)) {
                         ml = LZO_MINMATCH + count_eq(src, ip + 4, match + 4, matchlimit);   /* :159, no back-extension */
+                        if (mmlo && !(ml - LZO_MINMATCH >= mmlo || ip - match < LZO_16BIT_OFFSET)) break;     /* fastbig.h:145 */
                         continue;
                     }
                 }

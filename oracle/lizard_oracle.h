@@ -13,7 +13,7 @@
  *
  * Oracle definition: per-block output of Lizard_compress_extState() on a zero-filled
  * state.  Supported levels: 10, 11, 30, 31 (fastSmall / fast + fastLZ4 codewords), 13..17, 34..38 (hashChain +
- * fastLZ4 codewords), 12, 32, 33 (noChain + fastLZ4 codewords), 21, 22, 41, 42 (priceFast + LIZv1 codewords); levels >= 30
+ * fastLZ4 codewords), 12, 32, 33 (noChain + fastLZ4 codewords), 20, 40 (fastBig + LIZv1 codewords), 21, 22, 41, 42 (priceFast + LIZv1 codewords); levels >= 30
  * add the huff0 stage.
  */
 #ifndef LIZARD_ORACLE_H

@@ -49,13 +49,13 @@ extern "C" int emul_compress_block(const void* src, int n, void* dst, int level,
     if (level >= 34 && level <= 38) base = level - 21;
     const bool ncLevel = level == 12 || level == 32 || level == 33;       // noChain: the hashChain kernels with one candidate per search
     const bool hcLevel = (base >= 13 && base <= 17) || ncLevel;
-    int hashLog = ncLevel ? (level == 32 ? 14 : 18) : base == 10 ? 12 : base == 11 ? 18 : base == 21 ? 14 : base == 22 ? 18 : hcLevel ? 18 : 0;
+    int hashLog = ncLevel ? (level == 32 ? 14 : 18) : base == 10 ? 12 : base == 11 ? 18 : base == 20 ? 14 : base == 21 ? 14 : base == 22 ? 18 : hcLevel ? 18 : 0;
     if (!hashLog) return -1;
     if (hcLevel && (size_t)n > kHcMaxBlock) return -1;
     a.src = (const u8*)src; a.n = (u32)n; a.dst = (u8*)dst; a.level = (u32)level; a.result = 0;
     // odd seeds run the u32-slot (global-memory) table layout of the mixed-residency kernels; seeds = 2 mod 4 the packed
     // 18 + 6 bit LDS table of the priceFast kernel for blocks up to 256 KiB; the others the u32-slot LDS form
-    a.tabKind = ((base == 21 || base == 22 || base == 10) && (seed & 1u)) ? LZ_TABKIND_GLOBAL
+    a.tabKind = (base == 20 || ((base == 21 || base == 22 || base == 10) && (seed & 1u))) ? LZ_TABKIND_GLOBAL
               : (base == 21 && n <= (1 << 18) && (seed & 3u) == 2u) ? LZ_TABKIND_LDS18 : LZ_TABKIND_LDS;
     a.table = (u32*)aligned_alloc(64, (sizeof(u32) << hashLog) + 64);
     a.tag = (u8*)malloc(8192);
@@ -80,6 +80,7 @@ extern "C" int emul_compress_block(const void* src, int n, void* dst, int level,
     case 16: case 17:          lzemu::run_wave(huf ? entry_block<LZ_PARSER_HASHCHAIN, 18, 4, true> : entry_block<LZ_PARSER_HASHCHAIN, 18, 4, false>, &a, seed); break;
     case 10: lzemu::run_wave(huf ? entry_block<LZ_PARSER_FAST, 12, 0, true> : entry_block<LZ_PARSER_FAST, 12, 0, false>, &a, seed); break;
     case 11: lzemu::run_wave(huf ? entry_block<LZ_PARSER_FAST, 18, 0, true> : entry_block<LZ_PARSER_FAST, 18, 0, false>, &a, seed); break;
+    case 20: lzemu::run_wave(huf ? entry_block<LZ_PARSER_FASTBIG, 14, 11, true> : entry_block<LZ_PARSER_FASTBIG, 14, 10, false>, &a, seed); break;
     case 21: lzemu::run_wave(huf ? entry_block<LZ_PARSER_PRICEFAST, 14, 12, true> : entry_block<LZ_PARSER_PRICEFAST, 14, 12, false>, &a, seed); break;
     default: lzemu::run_wave(huf ? entry_block<LZ_PARSER_PRICEFAST, 18, 12, true> : entry_block<LZ_PARSER_PRICEFAST, 18, 12, false>, &a, seed); break;
     }

@@ -56,7 +56,7 @@ static int check_one(const unsigned char* src, int n, int level)
 int main(int argc, char** argv)
 {
     static const int sizes[] = { 1, 20, 21, 100, 4096, 65537, 131072, 131073, 262144, 300000 };
-    static const int levels[] = { 10, 30, 11, 31, 21, 41, 22, 42, 13, 14, 15, 16, 17, 34, 35, 36, 37, 38, 12, 32, 33 };
+    static const int levels[] = { 10, 30, 11, 31, 21, 41, 22, 42, 13, 14, 15, 16, 17, 34, 35, 36, 37, 38, 12, 32, 33, 20, 40 };
     int nb = argc > 1 ? atoi(argv[1]) : 512, bs = 262144, fails = 0;
     int only = argc > 2 ? atoi(argv[2]) : 0;          /* restrict to one level */
     int reps = argc > 3 ? atoi(argv[3]) : 1;          /* repeat the batch (profiling) */

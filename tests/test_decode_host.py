@@ -115,7 +115,7 @@ def my_decode(L, comp, cap):
 
 SMALL = [(n, d) for n, d in util.corpus(small=True)] + [("text", dict(util.corpus())["text"]), ("alpha4", dict(util.corpus())["alpha4"]),
                                                         ("zeros300k", bytes(300000)), ("random256k", dict(util.corpus())["random256k"])]
-GPU_LEVELS = [10, 11, 12, 13, 14, 15, 16, 17, 21, 22, 30, 31, 32, 33, 34, 35, 36, 37, 38, 41, 42]
+GPU_LEVELS = [10, 11, 12, 13, 14, 15, 16, 17, 20, 21, 22, 30, 31, 32, 33, 34, 35, 36, 37, 38, 40, 41, 42]
 
 
 def test_decodes_oracle_blocks(lib):

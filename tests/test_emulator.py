@@ -14,7 +14,7 @@ import util
 with open(os.path.join(util.GOLDEN_DIR, "reference_vectors.json")) as f:
     GOLDEN = json.load(f)
 
-EMUL_LEVELS = [10, 11, 21, 22, 30, 31, 41, 42]
+EMUL_LEVELS = [10, 11, 20, 21, 22, 30, 31, 40, 41, 42]
 
 
 def emul_compress(data, level, seed=1):
@@ -35,13 +35,13 @@ def test_emulated_kernel_vs_golden(level):
         assert len(out) == g["size"] and util.sha(out) == g["sha256"], (name, level)
 
 
-@pytest.mark.parametrize("level", [10, 30, 21, 11, 22, 13, 36])
+@pytest.mark.parametrize("level", [10, 30, 21, 11, 22, 13, 36, 20, 40, 12])
 def test_emulated_kernel_long_range(level):
     """Window-edge / position-wrap adversaries and multi-MiB blocks (tests/util.corpus_long): all of them at the BASELINE levels,
     every third one (a different third per level) at one level of each other kernel family."""
     cases = util.corpus_long()
-    if level not in (10, 30, 21):
-        cases = cases[level % 3::3]
+    if level not in (10, 30, 21, 20):
+        cases = cases[level % 3::3] + [c for c in cases if c[0] == "longoff_rule"]
     for name, data in cases:
         g = GOLDEN["cases"][name]["out"][str(level)]
         out = emul_compress(data, level, seed=len(name))
@@ -274,10 +274,11 @@ def test_emulated_fast18_block_beyond_22_bit_positions():
         assert emul_compress(data, 11, seed) == want, seed
 
 
-@pytest.mark.parametrize("level,seeds", [(21, (1, 4)), (22, (1, 3))])
+@pytest.mark.parametrize("level,seeds", [(21, (1, 4)), (22, (1, 3)), (20, (1,))])
 def test_emulated_pricefast_block_beyond_24_bit_positions(level, seeds):
-    """Levels 21/22/41/42 keep positions modulo 2^24 in their u32 slots and re-stamp dead slots every 2^22 positions: a block of
-    more than 16 MiB, both residences of the table (LDS / global memory; level 22 with and without the occupancy summary)."""
+    """Levels 21/22/41/42 (and 20/40, whose fastBig parser uses the same global-memory slots) keep positions modulo 2^24 in their u32
+    slots and re-stamp dead slots every 2^22 positions: a block of more than 16 MiB, both residences of the table (LDS / global
+    memory; level 22 with and without the occupancy summary)."""
     data = _beyond_width_case(1 << 24, 9)
     want = util.oracle_compress(data, level)
     for seed in seeds:
@@ -384,6 +385,29 @@ def test_emulated_pricefast_chained_paths_are_reached():
     missing = [v for k, v in names.items() if out[k] == 0]
     assert not missing, missing
     assert out[48] > 2 * out[51] and out[55] < out[48] + out[51]            # most sequences come from registers; more than one per round
+
+
+def test_emulated_fastbig_long_offset_rule_paths_are_reached():
+    """Levels 20 / 40 (lz_fastbig.h): a candidate 65 536 or more back counts only when forward count + backward extension reach 16
+    (lizard_parser_fastbig.h:92-98; no backward extension in the post-match probe, :143-146).  The lanes decide that from the bytes
+    they fetched, and the undecided ones in front of the first accepting lane are measured one by one.  tests/util.longoff_rule_case
+    puts matches on both sides of the rule behind a 66 000-byte run; the emulator's LZ_STAT marks must show every path taken, with
+    the output the compiled reference's (golden vector)."""
+    E = util.emulator()
+    out = (ctypes.c_ulonglong * 64)()
+    E.emul_stats(out, 1)
+    data = util.longoff_rule_case()
+    for level in (20, 40):
+        g = GOLDEN["cases"]["longoff_rule"]["out"][str(level)]
+        got = emul_compress(data, level, seed=level)
+        assert len(got) == g["size"] and util.sha(got) == g["sha256"], level
+        assert got == util.oracle_compress(data, level)
+    E.emul_stats(out, 1)
+    names = {1: "long-offset lane accepted from its fetched bytes", 2: "long-offset lane refused from its fetched bytes",
+             3: "undecided lane measured and accepted", 4: "undecided lane measured and refused",
+             5: "post-match probe wins behind a long offset", 6: "long-offset winner with a backward extension"}
+    missing = [v for k, v in names.items() if out[k] == 0]
+    assert not missing, (missing, [int(out[k]) for k in names])
 
 
 def test_emulated_chained_rounds_on_generator_data():

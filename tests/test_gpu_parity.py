@@ -87,12 +87,12 @@ def test_blocks_above_4mib(L):
     wave, so the bulk of it is a run (cheap to parse) between two copies of the same data exactly one position width + 100
     apart.  hashChain keeps full positions; its per-wave work area grows with the block."""
     data = util.datagen((5 << 20) + 123, 0.5, 0.0, 31) + bytes(300000) + util.datagen(1 << 20, 0.2, 0.0, 32)
-    for level in (10, 30, 21, 11, 22, 13):
+    for level in (10, 30, 21, 11, 22, 13, 20):
         out, r = gpu_compress(L, data, level)
         assert out == util.oracle_compress(data, level), level
     x = util.datagen(600000, 0.5, 0.0, 9)
     big = x + bytes((1 << 24) + 100 - len(x)) + x + util.datagen(300000, 0.4, 0.0, 10)       # 17.1 MiB
-    for level in (11, 21, 41, 22, 31, 10, 13, 36):
+    for level in (11, 21, 41, 22, 31, 10, 13, 36, 20, 40, 12):
         out, r = gpu_compress(L, big, level)
         assert out == util.oracle_compress(big, level), level
     assert L.LizardGPU_maxBlockSize(11) == L.LizardGPU_maxBlockSize(10) == L.LizardGPU_maxBlockSize(42) == L.LizardGPU_maxBlockSize(13) == 0x7E000000
@@ -102,7 +102,7 @@ def test_sweeps_due_inside_long_matches(L):
     """The shape of the round-3 soak finding at EVERY modular-position table, on the GPU: long matches (a run, a periodic stretch:
     one match per sub-block) carry the position across the table's sweep points, and what follows probes slots whose entries are
     one position width + 100 old — 100 modulo the width — with the same bytes and the same check bits.  Levels 10/30: 2^17,
-    sweep every 2^15 (the original bug); 11/31: 2^22, sweep every 2^20; 21/41/22/42: 2^24, sweep every 2^22."""
+    sweep every 2^15 (the original bug); 11/31: 2^22, sweep every 2^20; 20/40/21/41/22/42: 2^24, sweep every 2^22."""
     import random
     rnd = random.Random(17)
 
@@ -125,7 +125,7 @@ def test_sweeps_due_inside_long_matches(L):
     # priceFast: offsets up to 4 MiB — a 3 MiB pattern repeated (every sub-block one off24 match across the sweeps at 2^22, 2^23, ...)
     pat = rnd.randbytes(3 << 20)
     data = pat * 6 + util.datagen(100000, 0.5, 0.0, 7)                       # 18.1 MiB: beyond 2^24 positions
-    for level in (21, 42):
+    for level in (21, 42, 20):
         out, r = gpu_compress(L, data, level)
         assert out == util.oracle_compress(data, level), ("3 MiB period", level)
 

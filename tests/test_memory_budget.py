@@ -11,7 +11,7 @@ import util
 
 C = ctypes
 GIB = 1 << 30
-LEVELS = [10, 30, 11, 31, 21, 41, 22, 42, 13, 14, 15, 16, 17, 34, 35, 36, 37, 38, 12, 32, 33]
+LEVELS = [10, 30, 11, 31, 21, 41, 22, 42, 13, 14, 15, 16, 17, 34, 35, 36, 37, 38, 12, 32, 33, 20, 40]
 
 
 @pytest.fixture(scope="module")

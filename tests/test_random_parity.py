@@ -11,7 +11,7 @@ import pytest
 import util
 from test_emulator import emul_compress
 
-LEVELS = [10, 11, 12, 13, 14, 15, 16, 17, 21, 22, 30, 31, 32, 33, 34, 35, 36, 37, 38, 41, 42]
+LEVELS = [10, 11, 12, 13, 14, 15, 16, 17, 20, 21, 22, 30, 31, 32, 33, 34, 35, 36, 37, 38, 40, 41, 42]
 
 
 def make_case(rng, max_size):

@@ -177,7 +177,42 @@ def corpus_long():
         out.append((name, bytes(base)))
     out.append(("p50_4m", datagen(4 << 20, 0.5, 0.0, 5)))
     out.append(("p20_2m", datagen(2 << 20, 0.2, 0.0, 6)))
+    out.append(("longoff_rule", longoff_rule_case()))
     return out
+
+
+def longoff_rule_case():
+    """Matches 65 536 or more bytes back whose length sits around the LIZv1 levels' long-offset rule (minMatchLongOff 16: fastBig counts
+    the backward extension into it, lizard_parser_fastbig.h:92-98, its post-match probe :143-146 and priceFast :69 do not).
+    Layout: a dictionary of groups B_i (24 random bytes) + C_i (40) + 16 zeros (a short match: the fast parsers' step goes back to 1, so
+    every position of the next group is inserted), then every B_i once more (now the LAST position of B_i's hashes is not followed by
+    C_i: a later copy of B_i's tail + C_i's head is found at C_i's head and extended backwards), a run of 66 000 zeros (one match:
+    nothing inside is inserted), then per group a spacer of 0 or 20 random bytes (0: the copy starts at a post-match probe) and
+    B_i[-b:] + C_i[:L] with b + L on both sides of the rule; then copies of C_k[:L] behind spacers of thousands of noise bytes."""
+    rnd = random.Random(2016)
+    combos = [(sp, b, L) for sp in (0, 20) for b in (0, 2, 8, 9, 12) for L in (8, 12, 15, 16, 19, 20, 21, 24, 30)][::3]
+    B = [rnd.randbytes(24) for _ in combos]
+    C = [rnd.randbytes(40) for _ in combos]
+    z16 = b"\0" * 16
+    buf = bytearray(rnd.randbytes(8))
+    for i in range(len(combos)):
+        buf += B[i] + C[i] + z16
+    for i in range(len(combos)):
+        buf += B[i] + rnd.randbytes(4) + z16
+    buf += b"\0" * 66000
+    for i, (sp, b, L) in enumerate(combos):
+        buf += rnd.randbytes(sp) + (B[i][24 - b:] if b else b"") + C[i][:L] + z16
+    # ... and copies the parser ENTERS `off` bytes in, because its step has grown past `off` over a long spacer of noise: the match is
+    # extended backwards to the copy's start, and with off >= 8 the 8 bytes a lane fetches behind its position do not say how far.
+    # The spacer's length puts a visit of the schedule (fast.h:75-82: s_0 = 1, s_j = (63 + j) >> 6) exactly `off` bytes into the copy.
+    def visit_off(v):
+        return sum(1 if j == 0 else (63 + j) >> 6 for j in range(v))
+    for k, (off, L) in enumerate([(9, 20), (9, 19), (10, 21), (12, 20), (9, 26), (8, 20), (7, 20)]):
+        v = 64 * (off + 1) + 2                                 # the step in front of visit v is off + 1
+        spacer = 1 + visit_off(v) - off                        # behind a match that ends at `ip` the run starts at ip + 1
+        buf += b"\x55" + rnd.randbytes(spacer - 1) + C[k][:L] + z16
+    buf += rnd.randbytes(100)
+    return bytes(buf)
 
 
 # ---- frames (lizard_frame.h:111-125 LizardF_preferences_t == LizardGPU_framePrefs_t) -------------------
