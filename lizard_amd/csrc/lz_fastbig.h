@@ -16,8 +16,16 @@
 // of the bytes every candidate lane fetches anyway (24 forward, 8 backward); a lane whose lengths those bytes do not decide is
 // "undecided", and the undecided lanes in front of the first accepting one are measured with the wave-wide helpers, in lane order,
 // before the winner is taken (rare: long offsets with borderline lengths).
-// One sequence per round (the chained rounds of levels 10 / 11 are not carried over: behind a sequence the anchor moves, and with
-// it the backward room of every long-offset lane).
+// Several sequences out of one round, as at levels 10 / 11 (lz_block.h, "More than one sequence per round"): in the first round of a
+// run the lanes behind the winner hold the consecutive positions behind it, so when the winner's lengths come out of its fetched
+// bytes the reference's next steps — put(ip-2), the probe of ip (fastbig.h:133-160), the visits ip+1, ... of the next run — are
+// those lanes, provided none of them took its slot's value from a lane inside the match.  What differs from level 11: behind a
+// sequence the anchor has moved, and with it the backward room of every long-offset lane, so the accept test of the lanes from the new
+// ip on is made again with the new anchor (the lane of ip itself is a post-match probe: no backward extension); an undecided lane in
+// front of the next accepting one ends the chain.
+#ifndef LZ_FASTBIG_CHAIN
+#define LZ_FASTBIG_CHAIN 1
+#endif
 // Sequences go through lz_pricefast.h's LIZv1 list (lz_seq_push_liz, lz_seq_sizes_liz, lz_encode_lizv1).
 // Included from lz_block.h behind lz_pricefast.h.
 #pragma once
@@ -67,6 +75,7 @@ LZ_DEV void lz_parse_fastbig(const u8* src, u32 S, u32 E, const LzTab32G& table,
             const u32 mine = TAB::make(p, TAB::chkOf(first4));
             u32 e = table.get(valid ? h : 0u, p);                    // fastbig.h:81: the slot before this round
             u64 grp = laneBit;                                       // lanes of this round on my table slot
+            u32 jPrev = 64u;                                         // the lane my `e` came from (64 = the table)
             {
                 const u32 ti = h & tagMask;
                 if (valid) tag[ti] = (u8)lane;
@@ -86,7 +95,7 @@ LZ_DEV void lz_parse_fastbig(const u8* src, u32 S, u32 E, const LzTab32G& table,
                     const u64 prev = grp & lanesBelow;
                     const u32 j = prev ? 63u - lz_clz64(prev) : lane;
                     const u32 ej = lz_shfl(mine, j);                 // the put of the closest lower lane on my slot (:83, unconditional)
-                    if (prev) e = ej;
+                    if (prev) { e = ej; jPrev = j; }
                 }
             }
             // candidate test, fastbig.h:85, :90 (check bits first: they decide whether any bytes are fetched)
@@ -118,7 +127,8 @@ LZ_DEV void lz_parse_fastbig(const u8* src, u32 S, u32 E, const LzTab32G& table,
             lz_pin(fwd); lz_pin(cbk);
             // the long-offset rule, fastbig.h:96 / :145: (forward count behind the first 4 bytes) + (backward extension) >= 16.
             // The post-match probe (slot 1 of a special run) does not extend backwards.
-            const bool noBack = special != 0u && v0 == 0u && lane == 1u;
+            u32 probeLane = (special != 0u && v0 == 0u) ? 1u : 64u;  // uniform: the lane that is a post-match probe
+            const bool noBack = lane == probeLane;
             const u32 roomB = noBack ? 0u : ((p - anchor) < ep ? (p - anchor) : ep);   // :94 both bounds (anchor <= p for every probing slot)
             const bool backExact = roomB <= cbk || (haveBack && cbk < 8u);
             const u32 backLB = backExact ? (cbk < roomB ? cbk : roomB) : (haveBack ? 8u : 0u);
@@ -130,7 +140,7 @@ LZ_DEV void lz_parse_fastbig(const u8* src, u32 S, u32 E, const LzTab32G& table,
             u64 undMask = lz_ballot(undecided);
             // (emulator build: LZ_STAT 1 a long-offset lane accepted from the fetched bytes, 2 refused from them, 3 / 4 an undecided lane
             //  measured and accepted / refused, 5 a winner that is the post-match probe behind a long offset, 6 a long-offset winner
-            //  with a backward extension)
+            //  with a backward extension, 7 a sequence pushed from inside a round)
             if (lz_ballot(accept && !shortOff)) LZ_STAT(1);
             if (lz_ballot(ok4 && !accept && !undecided)) LZ_STAT(2);
             u32 exLane = 64u, exF = 0, exB = 0;                      // a winner measured below: its exact lengths
@@ -139,7 +149,7 @@ LZ_DEV void lz_parse_fastbig(const u8* src, u32 S, u32 E, const LzTab32G& table,
                 if (okMask && j > lz_ctz64(okMask)) break;
                 undMask &= undMask - 1ull;
                 const u32 Pj = lz_readlane(p, j), Mj = lz_readlane(ep, j);
-                const bool nbj = special != 0u && v0 == 0u && j == 1u;
+                const bool nbj = j == probeLane;
                 const u32 f = 4u + lz_count_fwd(src, Pj + 4u, Mj + 4u, matchlimit);
                 const u32 b = nbj ? 0u : lz_count_back(src, Pj, Mj, anchor);
                 if (f - 4u + b >= LZ_MM_LONGOFF) { LZ_STAT(3); okMask |= 1ull << j; exLane = j; exF = f; exB = b; break; }
@@ -148,7 +158,44 @@ LZ_DEV void lz_parse_fastbig(const u8* src, u32 S, u32 E, const LzTab32G& table,
             const u64 validMask = lz_ballot(valid);                  // uniform, a prefix of lanes
             u32 w = 0;
             u64 commit = validMask;
-            if (okMask) { w = lz_ctz64(okMask); commit = validMask & (~0ull >> (63u - w)); }
+            if (okMask) {
+                w = lz_ctz64(okMask); commit = validMask & (~0ull >> (63u - w));
+#if LZ_FASTBIG_CHAIN
+                u64 deadMask = 0;                                    // lanes inside the matches of chained sequences
+                while (v0 == 0u) {                                   // first round of a run: consecutive positions behind the winner
+                    const u32 Pw = lz_readlane(p, w), Mw = lz_readlane(ep, w);
+                    const u32 fw = w == exLane ? exF : lz_readlane(fwd, w);
+                    if (fw == 0xFFFFu) break;
+                    const u32 bk = w == probeLane ? 0u : w == exLane ? exB : lz_back_from(lz_readlane(cbk, w), Pw, Mw, anchor);
+                    if (bk == 0xFFFFu) break;
+                    const u32 ipn = Pw + fw, l1 = w + fw;            // fastbig.h:128: ip behind the sequence, and its lane
+                    if (ipn > mflimit || l1 > 63u) break;
+                    const u64 from1 = ~0ull << l1;
+                    // the accept test of the lanes from ip on, with the anchor at ip (:94: ip + back > anchor) and lane l1 as the
+                    // post-match probe (:143-146: no backward extension)
+                    const u32 rb2 = lane == l1 ? 0u : ((p - ipn) < ep ? (p - ipn) : ep);      // (lanes below l1: garbage, masked off)
+                    const bool be2 = rb2 <= cbk || (haveBack && cbk < 8u);
+                    const u32 bl2 = be2 ? (cbk < rb2 ? cbk : rb2) : (haveBack ? 8u : 0u);
+                    const bool acc2 = ok4 && (shortOff || fwdLB - 4u + bl2 >= LZ_MM_LONGOFF);
+                    const bool und2 = ok4 && !acc2 && !(fwd != 0xFFFFu && be2);
+                    const u64 ok2 = lz_ballot(acc2) & from1;
+                    if (!ok2) break;
+                    const u32 w2 = lz_ctz64(ok2);                    // the next accepting lane: probe of ip or a visit of the next run
+                    if (lz_ballot(und2) & from1 & (~0ull >> (63u - w2))) break;    // its lengths would decide: left to the next round
+                    const u64 put2 = 1ull << (l1 - 2u);              // put(ip-2), fastbig.h:133
+                    const u64 dead2 = deadMask | ((from1 ^ (~0ull << (w + 1u))) & ~put2);
+                    const u64 readers = put2 | (from1 & (~0ull >> (63u - w2)));
+                    // a lane whose slot value came from the registers of a lane inside the match read a put that never happened
+                    const bool stale = jPrev < 64u && ((dead2 >> jPrev) & 1ull);
+                    if (lz_ballot(stale) & readers) break;
+                    LZ_STAT(7);
+                    if (Pw - Mw >= LZ_16BIT_OFFSET) { if (w == probeLane) LZ_STAT(5); else if (bk) LZ_STAT(6); }
+                    lz_seq_push_liz(st, Pw - bk - anchor, fw + bk, Pw - Mw);      // fastbig.h:127
+                    anchor = ipn; probeLane = l1; exLane = 64u;
+                    deadMask = dead2; commit |= readers; w = w2;
+                }
+#endif
+            }
             // settle: the last committed lane of every table slot stores its entry; slots behind the winner never happened
             {
                 const u64 c = grp & commit;
@@ -161,12 +208,11 @@ LZ_DEV void lz_parse_fastbig(const u8* src, u32 S, u32 E, const LzTab32G& table,
                 if (w == exLane) { ml = exF; back = exB; }
                 else {
                     ml = lz_readlane(fwd, w);
-                    const bool nbw = special != 0u && v0 == 0u && w == 1u;
-                    back = nbw ? 0u : lz_back_from(lz_readlane(cbk, w), P, M, anchor);
+                    back = w == probeLane ? 0u : lz_back_from(lz_readlane(cbk, w), P, M, anchor);
                     if (ml == 0xFFFFu) ml = 4u + lz_count_fwd(src, P + 4u, M + 4u, matchlimit);     // fastbig.h:93
                     if (back == 0xFFFFu) back = lz_count_back(src, P, M, anchor);                    // :95
                 }
-                if (P - M >= LZ_16BIT_OFFSET) { if (special != 0u && v0 == 0u && w == 1u) LZ_STAT(5); else if (back) LZ_STAT(6); }
+                if (P - M >= LZ_16BIT_OFFSET) { if (w == probeLane) LZ_STAT(5); else if (back) LZ_STAT(6); }
                 break;
             }
             if (validMask != ~0ull) goto tail;                       // ran into mflimit without a match (:79)

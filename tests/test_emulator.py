@@ -405,7 +405,8 @@ def test_emulated_fastbig_long_offset_rule_paths_are_reached():
     E.emul_stats(out, 1)
     names = {1: "long-offset lane accepted from its fetched bytes", 2: "long-offset lane refused from its fetched bytes",
              3: "undecided lane measured and accepted", 4: "undecided lane measured and refused",
-             5: "post-match probe wins behind a long offset", 6: "long-offset winner with a backward extension"}
+             5: "post-match probe wins behind a long offset", 6: "long-offset winner with a backward extension",
+             7: "sequence pushed from inside a round"}
     missing = [v for k, v in names.items() if out[k] == 0]
     assert not missing, (missing, [int(out[k]) for k in names])
 
