@@ -37,7 +37,7 @@ validate)
   find $O/rocprof -name "*.csv" -size +1M -delete; find $O/rocprof -name "*.db" -delete
   bash scripts/gpu_traffic.sh $TAG "10 262144 65536" "10 4194304 6656" "30 262144 16384" "21 262144 16384" "11 262144 16384" "13 262144 16384" > $O/traffic.log 2>&1
   grep -E "^L" $O/traffic.log | tee -a $O/summary.txt
-  for l in 11 31 13 14 15 16 17 35 22 41 42; do timeout 300 tests/gpu_bench $l 262144 16384 2 50 1024 2>&1 | tail -1 | tee -a $O/summary.txt; done ;;
+  for l in 11 31 12 32 33 13 14 15 16 17 35 37 20 40 22 41 42; do timeout 300 tests/gpu_bench $l 262144 16384 2 50 1024 2>&1 | tail -1 | tee -a $O/summary.txt; done ;;
 validate_slim)
   # the validation pass when GPU minutes are short: GPU tests, smoke, bench line, rocprofv3 of the headline configuration alone,
   # counter passes of the four bench configurations, one gpu_bench line per remaining level
@@ -49,7 +49,7 @@ validate_slim)
   find $O/rocprof_headline -name "*.csv" -size +1M -delete; find $O/rocprof_headline -name "*.db" -delete
   bash scripts/gpu_traffic.sh $TAG "10 262144 65536" "10 4194304 6656" "30 262144 16384" "21 262144 16384" > $O/traffic.log 2>&1
   grep -E "^L" $O/traffic.log | tee -a $O/summary.txt
-  for l in 11 31 13 14 15 16 17 35 37 22 41 42; do timeout 300 tests/gpu_bench $l 262144 16384 2 50 1024 2>&1 | tail -1 | tee -a $O/summary.txt; done ;;
+  for l in 11 31 12 32 33 13 14 15 16 17 35 37 20 40 22 41 42; do timeout 300 tests/gpu_bench $l 262144 16384 2 50 1024 2>&1 | tail -1 | tee -a $O/summary.txt; done ;;
 rocprof_all)
   # rocprofv3 kernel stats over EVERY BASELINE configuration of the bench line in one CSV
   ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/rocprof -o bench -- python $R/bench.py --no-cpu --steps 3 --warmup 1 > $R/$O/bench_under_rocprof.json 2> $R/$O/rocprof.err; echo "rocprof rc=$?" ) | tee -a $O/summary.txt

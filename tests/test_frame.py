@@ -83,7 +83,7 @@ def test_frame_refusals_need_no_gpu(lib):
     p = util.frame_prefs(10, 1, 0, 0)
     assert lib.LizardGPU_compressFrame(dst, 1000, data, len(data), ctypes.byref(p)) == err(11)
     # a level without a GPU kernel is refused, not emulated
-    p = util.frame_prefs(12, 1, 0, 0)
+    p = util.frame_prefs(23, 1, 0, 0)                       # lowestPrice: one of the 17 price-based levels
     assert lib.LizardGPU_compressFrame(dst, cap, data, len(data), ctypes.byref(p)) == err(5)
     assert lib.LizardGPU_frameIsError(err(5)) and not lib.LizardGPU_frameIsError(12345)
 

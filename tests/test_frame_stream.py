@@ -113,7 +113,7 @@ def test_stream_refusals_need_no_gpu(lib):
     dst = ctypes.create_string_buffer(64)
     assert lib.LizardGPU_compressBegin(ctx, dst, 10, ctypes.byref(util.frame_prefs(10, 1, 0, 0))) == err(11)      # header room
     assert lib.LizardGPU_compressBegin(ctx, dst, 64, ctypes.byref(util.frame_prefs(10, 1, 0, 0, block_mode=0))) == err(3)   # linked
-    assert lib.LizardGPU_compressBegin(ctx, dst, 64, ctypes.byref(util.frame_prefs(12, 1, 0, 0))) == err(5)      # no GPU kernel
+    assert lib.LizardGPU_compressBegin(ctx, dst, 64, ctypes.byref(util.frame_prefs(23, 1, 0, 0))) == err(5)      # no GPU kernel (lowestPrice)
     for level in (11, 21, 13):                                 # 16 MiB (and larger) frame blocks are taken at every GPU level since round 3
         c2 = ctypes.c_void_p()
         assert lib.LizardGPU_createCompressionContext(ctypes.byref(c2)) == 0

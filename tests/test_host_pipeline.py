@@ -92,14 +92,14 @@ def test_errors_are_per_thread_and_cleared_on_success(L):
 
     def worker():
         seen["before"] = L.LizardGPU_lastError()
-        L.LizardGPU_compressBlocks_host(src.ctypes.data, 1, 4096, 4096, out.ctypes.data, 8192, sizes.ctypes.data, 12)   # level 12: no kernel
+        L.LizardGPU_compressBlocks_host(src.ctypes.data, 1, 4096, 4096, out.ctypes.data, 8192, sizes.ctypes.data, 23)   # level 23 (lowestPrice): no kernel
         seen["after"] = L.LizardGPU_lastError()
 
     assert L.LizardGPU_compressBlocks_host(src.ctypes.data, 1, 4096, 5000, out.ctypes.data, 8192, sizes.ctypes.data, 10) == -3
     mine = L.LizardGPU_lastError()
     assert mine != b""
     t = threading.Thread(target=worker); t.start(); t.join()
-    assert seen["before"] == b"" and b"level 12" in seen["after"]
+    assert seen["before"] == b"" and b"level 23" in seen["after"]
     assert L.LizardGPU_lastError() == mine                      # the other thread's failure did not touch this thread's text
     assert L.LizardGPU_compressBlocks_host(src.ctypes.data, 1, 4096, 4096, out.ctypes.data, 8192, sizes.ctypes.data, 10) == 0
     assert L.LizardGPU_lastError() == b""
@@ -112,4 +112,4 @@ def test_shutdown_and_recreate(L):
     L.LizardGPU_shutdown()
     b = api.compress_blocks(data, 131072, 11)
     assert a == b and a[0] == util.oracle_compress(data[:131072], 11)
-    assert L.LizardGPU_deviceCount() >= 1 and L.LizardGPU_maxBlockSize(11) == 0x7E000000 and L.LizardGPU_maxBlockSize(12) == 0
+    assert L.LizardGPU_deviceCount() >= 1 and L.LizardGPU_maxBlockSize(11) == 0x7E000000 and L.LizardGPU_maxBlockSize(12) == 0x7E000000 and L.LizardGPU_maxBlockSize(23) == 0

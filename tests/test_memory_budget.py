@@ -80,7 +80,7 @@ def test_degraded_calls_are_counted(L):
     lib = L
     lib.Lizard_compress.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
     assert lib.Lizard_compress(data, dst, len(data), 200000, 19) == 0        # level 19 (optimal parser) has no GPU kernel: 0, counted
-    assert lib.Lizard_compress(data, dst, len(data), 200000, 12) == 0
+    assert lib.Lizard_compress(data, dst, len(data), 200000, 23) == 0
     assert L.LizardGPU_degradedCalls() == n0 + 2
     assert lib.Lizard_compress(data, dst, len(data), 200000, 10) > 0         # a supported level is not counted
     assert L.LizardGPU_degradedCalls() == n0 + 2
