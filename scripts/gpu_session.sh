@@ -35,7 +35,7 @@ validate)
   find $O/rocprof_headline -name "*kernel_stats.csv" -exec cp {} $O/rocprofv3_kernel_stats_bench_headline_only.csv \;
   find $O/rocprof_headline -name "*.csv" -size +1M -delete; find $O/rocprof_headline -name "*.db" -delete
   find $O/rocprof -name "*.csv" -size +1M -delete; find $O/rocprof -name "*.db" -delete
-  bash scripts/gpu_traffic.sh $TAG "10 262144 65536" "10 4194304 6656" "30 262144 16384" "21 262144 16384" "11 262144 16384" "13 262144 16384" > $O/traffic.log 2>&1
+  bash scripts/gpu_traffic.sh $TAG "10 262144 65536" "10 4194304 6656" "30 262144 16384" "21 262144 16384" "11 262144 16384" "13 262144 16384" "20 262144 16384" "12 262144 16384" > $O/traffic.log 2>&1
   grep -E "^L" $O/traffic.log | tee -a $O/summary.txt
   for l in 11 31 12 32 33 13 14 15 16 17 35 37 20 40 22 41 42; do timeout 300 tests/gpu_bench $l 262144 16384 2 50 1024 2>&1 | tail -1 | tee -a $O/summary.txt; done ;;
 validate_slim)
