@@ -15,7 +15,7 @@ import pytest
 import util
 
 C = ctypes
-LEVELS = [10, 30, 21, 41, 11, 13, 17, 35, 22]
+LEVELS = [10, 30, 21, 41, 11, 13, 17, 35, 22, 20, 32]
 SIZES = [1, 19, 21, 100, 4096, 65537, 131072, 131073, 262144, 300000]
 
 
