@@ -939,7 +939,10 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
         hc.pre = kPre;
         if constexpr (kPre) lz_hc_hits(src, n, hc); else lz_hc_hits_plain(src, n, hc);
     }
-    else if constexpr (PARSER == LZ_PARSER_FASTBIG) { lz_pf_tab_fresh<HASHLOG>(pf32g); st.sweepAt = LZ_PF_SWEEP_EVERY; }
+    else if constexpr (PARSER == LZ_PARSER_FASTBIG) {            // with slot codes in LDS (wideOcc) a slot is only read after this block wrote it
+        if (wideOcc) lz_fb_codes_fresh<HASHLOG>(wideOcc); else lz_pf_tab_fresh<HASHLOG>(pf32g);
+        st.sweepAt = LZ_PF_SWEEP_EVERY;
+    }
     else if constexpr (kWide) { lz_tab_fresh<HASHLOG>(tabw); st.sweepAt = LzTabWide::kSweepEvery; }
     else if constexpr (PARSER == LZ_PARSER_FAST) {
         if (tabKind == LZ_TABKIND_GLOBAL) { lz_tab_fresh<HASHLOG>(tabw); st.sweepAt = LzTabWide::kSweepEvery; }
@@ -958,7 +961,7 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
         st.nlit = st.nflags = st.noff16 = st.noff24 = 0;      // Lizard_initBlock, :130-138
         st.nseq = 0; st.lastLits = 0;
         if constexpr (PARSER == LZ_PARSER_HASHCHAIN) lz_parse_hashchain(src, n, pos, pos + part, hc, st);
-        else if constexpr (PARSER == LZ_PARSER_FASTBIG) lz_parse_fastbig<HASHLOG, AUX>(src, pos, pos + part, pf32g, ws, st);
+        else if constexpr (PARSER == LZ_PARSER_FASTBIG) lz_parse_fastbig<HASHLOG, AUX>(src, pos, pos + part, pf32g, ws, wideOcc, st);
         else if constexpr (kWide)                    lz_parse_fast<HASHLOG>(src, pos, pos + part, tabw, st);
         else if constexpr (PARSER == LZ_PARSER_FAST) {
             if (tabKind == LZ_TABKIND_GLOBAL) lz_parse_fast<HASHLOG>(src, pos, pos + part, tabw, st);

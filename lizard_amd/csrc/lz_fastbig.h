@@ -27,11 +27,23 @@
 #define LZ_FASTBIG_CHAIN 1
 #endif
 // Sequences go through lz_pricefast.h's LIZv1 list (lz_seq_push_liz, lz_seq_sizes_liz, lz_encode_lizv1).
+//
+// Slot codes in LDS (`codes`, optional: 4 bits per slot, 8 KiB per wave at hashLog 14).  A round reads 64 slots and every slot is a
+// 128-byte line of its own: with sixteen waves per CU that is what the level costs (394 GB of fabric traffic per 4 GiB of input,
+// 5.2 TB/s, profiles/r06fin2_*).  Most of those reads find an entry that cannot match.  The code of a slot is 0 while nothing was put
+// there in this block, else the low four bits of the entry's check bits (0 written as 15); a probe whose own code differs never
+// reads the slot — its entry, if any, fails the check-bit test (:95 below) — and a slot with code 0 is never read at all, so the
+// table in global memory needs no clearing between blocks.  Exact: the code is written by the lane that writes the slot.
 // Included from lz_block.h behind lz_pricefast.h.
 #pragma once
 
+LZ_DEV u32 lz_fb_code(u32 chk8) { const u32 c = chk8 & 15u; return c ? c : 15u; }
+LZ_DEV u32 lz_fb_code_get(const u32* codes, u32 h) { return (codes[h >> 3] >> ((h & 7u) * 4u)) & 15u; }
+LZ_DEV void lz_fb_code_put(u32* codes, u32 h, u32 c) { lz_lds_mskor(&codes[h >> 3], 15u << ((h & 7u) * 4u), c << ((h & 7u) * 4u)); }
+template <int HASHLOG> LZ_DEV void lz_fb_codes_fresh(u32* codes) { for (u32 i = lz_lane(); i < (1u << HASHLOG) / 8u; i += 64u) codes[i] = 0u; lz_lds_sync(); }
+
 template <int HASHLOG, int TAGLOG>
-LZ_DEV void lz_parse_fastbig(const u8* src, u32 S, u32 E, const LzTab32G& table, u8* tag, LzStreams& st)
+LZ_DEV void lz_parse_fastbig(const u8* src, u32 S, u32 E, const LzTab32G& table, u8* tag, u32* codes, LzStreams& st)
 {
     typedef LzTab32G TAB;
     const u32 lane = lz_lane();
@@ -46,9 +58,15 @@ LZ_DEV void lz_parse_fastbig(const u8* src, u32 S, u32 E, const LzTab32G& table,
 
     if (S >= st.sweepAt) { table.sync(); lz_pf_tab_sweep<HASHLOG>(table, S); st.sweepAt = S + LZ_PF_SWEEP_EVERY; }
     table.sync();
-    if (lane == 0) { const u64 b0 = lz_ld64(src + S); table.set(lz_hash5<HASHLOG>(b0), TAB::make(S, TAB::chkOf((u32)b0))); }   // fastbig.h:61
+    if (lane == 0) {                                                 // fastbig.h:61
+        const u64 b0 = lz_ld64(src + S);
+        const u32 h0 = lz_hash5<HASHLOG>(b0), c0 = TAB::chkOf((u32)b0);
+        table.set(h0, TAB::make(S, c0));
+        if (codes) lz_fb_code_put(codes, h0, lz_fb_code(c0));
+    }
     lz_converge();
     table.sync();
+    lz_lds_sync();
 
     u32 ip = S + 1u;        // uniform: run start, or (special == 1) the post-match probe position
     u32 special = 0;        // uniform
@@ -72,8 +90,14 @@ LZ_DEV void lz_parse_fastbig(const u8* src, u32 S, u32 E, const LzTab32G& table,
             }
             const u32 first4 = (u32)bytes;
             const u32 h = lz_hash5<HASHLOG>(bytes);
-            const u32 mine = TAB::make(p, TAB::chkOf(first4));
-            u32 e = table.get(valid ? h : 0u, p);                    // fastbig.h:81: the slot before this round
+            const u32 myChk = TAB::chkOf(first4);
+            const u32 mine = TAB::make(p, myChk);
+            u32 e;                                                   // fastbig.h:81: the slot before this round
+            if (codes) {                                             // (uniform) only the lanes whose slot's code is theirs read the table
+                e = TAB::dead(p);
+                if (valid && !putOnly && lz_fb_code_get(codes, h) == lz_fb_code(myChk)) e = table.get(h, p);
+                lz_converge();
+            } else e = table.get(valid ? h : 0u, p);
             u64 grp = laneBit;                                       // lanes of this round on my table slot
             u32 jPrev = 64u;                                         // the lane my `e` came from (64 = the table)
             {
@@ -101,7 +125,7 @@ LZ_DEV void lz_parse_fastbig(const u8* src, u32 S, u32 E, const LzTab32G& table,
             // candidate test, fastbig.h:85, :90 (check bits first: they decide whether any bytes are fetched)
             const u32 age = TAB::age(p, TAB::pos(e));
             const u32 ep = p - age;
-            const bool cand = valid && !putOnly && TAB::chk(e) == TAB::chkOf(first4) && age >= LZ_MIN_OFFSET && age <= maxDist && age <= p - lowPos;
+            const bool cand = valid && !putOnly && TAB::chk(e) == myChk && age >= LZ_MIN_OFFSET && age <= maxDist && age <= p - lowPos;
             u64 cA = LZ_ANY64, cB = LZ_ANY64, pB = LZ_ANY64, cC = LZ_ANY64, pC = LZ_ANY64, cZ = LZ_ANY64, pZ = LZ_ANY64;
             const bool haveBack = cand && ep >= 8u;                  // then p >= 16 as well
             const bool have24 = p + 24u <= E;
@@ -199,10 +223,11 @@ LZ_DEV void lz_parse_fastbig(const u8* src, u32 S, u32 E, const LzTab32G& table,
             // settle: the last committed lane of every table slot stores its entry; slots behind the winner never happened
             {
                 const u64 c = grp & commit;
-                if (valid && (c >> lane) == 1ull) table.set(h, mine);
+                if (valid && (c >> lane) == 1ull) { table.set(h, mine); if (codes) lz_fb_code_put(codes, h, lz_fb_code(myChk)); }
                 lz_converge();
             }
             table.sync();
+            lz_lds_sync();
             if (okMask) {
                 P = lz_readlane(p, w); M = lz_readlane(ep, w);
                 if (w == exLane) { ml = exF; back = exB; }

@@ -208,13 +208,19 @@ __global__ __launch_bounds__(64 * LZ_WAVES_HC) void lz_hashchain_kernel(LzBatch 
     lz_wave_main<LZ_PARSER_HASHCHAIN, HLOG, SEARCHLEN, HUF, LZ_WAVES_HC, (HUF ? LZ_HUF_WS_WORDS : 1), 0>(a);
 }
 
-// levels 20 / 40: fastBig + LIZv1 (lz_fastbig.h), 2^14 u32 slots per wave in its global-memory slot (the slots of levels 21 / 41),
-// tag array of the rounds in LDS (with Huffman: the 2 KiB workspace doubles as it)
+// levels 20 / 40: fastBig + LIZv1 (lz_fastbig.h), 2^14 u32 slots per wave in its global-memory slot (the slots of levels 21 / 41);
+// in LDS per wave a 1 KiB tag array for the rounds and 8 KiB of slot codes (4 bits per slot: which slots are worth reading); the
+// Huffman workspaces of level 40 come from a pool of four
 #define LZ_WAVES_FASTBIG 16
+#ifndef LZ_FASTBIG_CODES
+#define LZ_FASTBIG_CODES 1                       // 0: every probe reads its slot (tuning variants; the table is cleared per block then)
+#endif
+#define LZ_FASTBIG_HUF_POOL 4
 template <bool HUF>
 __global__ __launch_bounds__(64 * LZ_WAVES_FASTBIG) void lz_fastbig14_kernel(LzBatch a)
 {
-    lz_wave_main<LZ_PARSER_FASTBIG, 14, (HUF ? 11 : 10), HUF, LZ_WAVES_FASTBIG, (HUF ? LZ_HUF_WS_WORDS : (1u << 10) / 4u), 0>(a);
+    lz_wave_main<LZ_PARSER_FASTBIG, 14, 10, HUF, LZ_WAVES_FASTBIG, (1u << 10) / 4u, 0, LZ_TABKIND_LDS, (HUF ? LZ_FASTBIG_HUF_POOL : 0),
+                 (LZ_FASTBIG_CODES ? 16 : 0)>(a);
 }
 
 // levels 21 / 41: priceFast + LIZv1, 2^14-slot table.  A wave whose table is in LDS is bound by the issue latency of its own

@@ -69,7 +69,7 @@ extern "C" int emul_compress_block(const void* src, int n, void* dst, int level,
     void* garbageTable = a.table;
     if (hcLevel) a.table = (u32*)hc_slot();
     a.maxBlock = (u32)kHcMaxBlock; a.poolMask = 0;
-    a.wideOcc = ((base == 11 || base == 22) && !(seed & 2u)) ? (u32*)malloc(8192 + 8) : nullptr;     // levels 11/31, 22/42: with and without the occupancy summary
+    a.wideOcc = ((base == 11 || base == 22 || base == 20) && !(seed & 2u)) ? (u32*)malloc(8192 + 8) : nullptr;     // levels 11/31, 22/42: with and without the occupancy summary; 20/40: with and without the slot codes
     if (a.wideOcc) memset(a.wideOcc, 0x77, 8192 + 8);
     a.hcRegion = (u32*)aligned_alloc(64, 4 * LZ_HC_REGION_WORDS + 64);
     memset(a.hcRegion, 0x3C, 4 * LZ_HC_REGION_WORDS);
@@ -80,7 +80,7 @@ extern "C" int emul_compress_block(const void* src, int n, void* dst, int level,
     case 16: case 17:          lzemu::run_wave(huf ? entry_block<LZ_PARSER_HASHCHAIN, 18, 4, true> : entry_block<LZ_PARSER_HASHCHAIN, 18, 4, false>, &a, seed); break;
     case 10: lzemu::run_wave(huf ? entry_block<LZ_PARSER_FAST, 12, 0, true> : entry_block<LZ_PARSER_FAST, 12, 0, false>, &a, seed); break;
     case 11: lzemu::run_wave(huf ? entry_block<LZ_PARSER_FAST, 18, 0, true> : entry_block<LZ_PARSER_FAST, 18, 0, false>, &a, seed); break;
-    case 20: lzemu::run_wave(huf ? entry_block<LZ_PARSER_FASTBIG, 14, 11, true> : entry_block<LZ_PARSER_FASTBIG, 14, 10, false>, &a, seed); break;
+    case 20: lzemu::run_wave(huf ? entry_block<LZ_PARSER_FASTBIG, 14, 10, true> : entry_block<LZ_PARSER_FASTBIG, 14, 10, false>, &a, seed); break;
     case 21: lzemu::run_wave(huf ? entry_block<LZ_PARSER_PRICEFAST, 14, 12, true> : entry_block<LZ_PARSER_PRICEFAST, 14, 12, false>, &a, seed); break;
     default: lzemu::run_wave(huf ? entry_block<LZ_PARSER_PRICEFAST, 18, 12, true> : entry_block<LZ_PARSER_PRICEFAST, 18, 12, false>, &a, seed); break;
     }

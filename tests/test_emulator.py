@@ -397,10 +397,10 @@ def test_emulated_fastbig_long_offset_rule_paths_are_reached():
     out = (ctypes.c_ulonglong * 64)()
     E.emul_stats(out, 1)
     data = util.longoff_rule_case()
-    for level in (20, 40):
+    for level, seed in ((20, 20), (40, 40), (20, 22), (40, 42)):       # seed bit 1: with / without the slot codes in LDS
         g = GOLDEN["cases"]["longoff_rule"]["out"][str(level)]
-        got = emul_compress(data, level, seed=level)
-        assert len(got) == g["size"] and util.sha(got) == g["sha256"], level
+        got = emul_compress(data, level, seed=seed)
+        assert len(got) == g["size"] and util.sha(got) == g["sha256"], (level, seed)
         assert got == util.oracle_compress(data, level)
     E.emul_stats(out, 1)
     names = {1: "long-offset lane accepted from its fetched bytes", 2: "long-offset lane refused from its fetched bytes",
