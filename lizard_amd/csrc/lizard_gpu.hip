@@ -317,6 +317,7 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
     else if (lv == 11 || lv == 31) W = LZ_WAVES_FAST18;
     else if (hcLevel)              W = LZ_WAVES_HC;
     else if (lv == 21 || lv == 41) W = pfSmall ? (huf ? LZ_PF18_W_HUF : LZ_PF18_W) : LZ_PF_W;
+    else if (lv == 20 || lv == 40) W = LZ_WAVES_FASTBIG;
     else                           W = LZ_PF22_W;
     if (!perGroup) perGroup = W;
     // Which arena?  (lizard_gpu_ctx.h, LzArena.)  The context's own unless this is a small launch on another stream than the one

@@ -211,7 +211,9 @@ __global__ __launch_bounds__(64 * LZ_WAVES_HC) void lz_hashchain_kernel(LzBatch 
 // levels 20 / 40: fastBig + LIZv1 (lz_fastbig.h), 2^14 u32 slots per wave in its global-memory slot (the slots of levels 21 / 41);
 // in LDS per wave a 1 KiB tag array for the rounds and 8 KiB of slot codes (4 bits per slot: which slots are worth reading); the
 // Huffman workspaces of level 40 come from a pool of four
+#ifndef LZ_WAVES_FASTBIG
 #define LZ_WAVES_FASTBIG 16
+#endif
 #ifndef LZ_FASTBIG_CODES
 #define LZ_FASTBIG_CODES 1                       // 0: every probe reads its slot (tuning variants; the table is cleared per block then)
 #endif
