@@ -17,7 +17,8 @@ barrier-bracketed timed region of exactly --steps steps, max over ranks.  The sa
 BASELINE configs with the same --steps / --warmup and reports them under "configs": level 21 and level 30 at
 16 384 x 256 KiB (configs[2..3]) and configs[4] in BOTH readings: weak scaling — 6 656 x 4 MiB blocks PER GPU, two per
 table-holding wave — and strong scaling — 4 096 x 4 MiB blocks in the WHOLE job (SURVEY 8d read literally), 4 096 / N per GPU, the
-same 4 096 blocks at every N ("scaling": "strong", "blocks_total"); "config1" is configs[0], the reference's own
+same 4 096 blocks at every N ("scaling": "strong", "blocks_total"), and — not a BASELINE config — level 20 (fastBig, LIZv1
+codewords; round 6) at 16 384 x 256 KiB with the same checks; "config1" is configs[0], the reference's own
 CPU-runnable case (64 MiB RDG_genBuffer P50 seed 0 in 256 KiB blocks, programs/bench.c's loop over Lizard_compress).
 Per config:
   roofline      achieved = algorithmic bytes per launch (input read once + compressed output written once,
@@ -488,6 +489,7 @@ def main():
         plan = [(10, 262144, args.blocks or 65536, "weak")]
         if not args.headline_only:
             plan += [(21, 262144, 16384, "weak"), (30, 262144, 16384, "weak"), (10, 4 << 20, 6656, "weak")]
+            plan += [(20, 262144, 16384, "weak")]          # not a BASELINE config: the fastBig level of round 6 (LIZv1 codewords), same checks
         if not args.headline_only or args.strong:
             plan += [(10, 4 << 20, max(1, args.strong_blocks // world), "strong")]
     max_in = max(nb * bs for _, bs, nb, _ in plan)
