@@ -91,9 +91,9 @@ def kernel_name(level, bs):
     if base == 22:
         return "lz_pricefast18_kernel<%s>" % huf
     if level == 32:
-        return "lz_hashchain_kernel<true, 5, 14>"
+        return "lz_hashchain_kernel<true, 6, 14>"
     if level in (12, 33):
-        return "lz_hashchain_kernel<%s, 5, 18>" % huf
+        return "lz_hashchain_kernel<%s, 6, 18>" % huf
     return "lz_hashchain_kernel<%s, %d, 18>" % (huf, 5 if base <= 15 else 4)
 
 

@@ -633,6 +633,24 @@ LZ_DEV u32 lz_hc_search(const u8* src, u32 nBlock, const LzHc& hc, u32 X, u32 iL
     return longest;
 }
 
+// One search of a noChain level (Lizard_InsertAndFindBestMatchNoChain nochain.h:28-80, wider == false; Lizard_InsertAndGetWiderMatchNoChain
+// :83-143, wider == true): ONE candidate, the head of X's bucket = X - prev[X], and every caller has read X's hit bit first — the
+// candidate lies inside the window, at least MIN_OFFSET back, and agrees with X in 4 bytes.  Nothing is left to test before the
+// lengths are measured, so forward count and backward extension come out of ONE memory trip (lz_count_both) where the general search
+// spends three in a row (chain word, 4-byte test, measurement); cw = X's chain word, out of the parse's register window when X lies
+// in it.  The guards below only matter for a caller without the hit bit (LZ_HC_SKIP_NOHIT 0 builds).
+LZ_DEV u32 lz_nc_search(const u8* src, u32 cw, u32 X, u32 iLow, u32 iHigh, u32 longest, bool wider, u32& ref, u32& start)
+{
+    const u32 d1 = cw & 0xFFFFu;
+    if (d1 < LZ_MIN_OFFSET) return longest;                      // no head inside the window (0; :49 / :103), or closer than MIN_OFFSET (:53 / :107)
+    const u32 m = X - d1;
+    u32 f, b;
+    lz_count_both(src, X, m, iHigh, wider ? iLow : X, f, b);     // (anchor X: the first search does not extend backwards)
+    if (f < 4u) return longest;                                  // :55 / :110
+    if (f + b > longest) { longest = f + b; ref = m - b; start = X - b; }      // :57-58 / :112-120
+    return longest;
+}
+
 // The hit bit of position X (uniform): out of the 4 096 positions of bits the outer loop holds in registers when X lies there,
 // else one word from memory.  A search at a position whose bit is clear — the first one or a "wider" one (hashchain.h:45-107,
 // :109-186: both test the 4 bytes AT the position, :73 / :146) — finds nothing: no walk, no candidate bytes, no memory trip.
@@ -649,6 +667,9 @@ LZ_DEV bool lz_hc_hit_at(const LzHc& hc, u64 bm, u32 bmBase, u32 X)
 }
 
 // Sub-block [S,E) of the block at src (hashchain.h:188-369).  The chain must have been built for the block.
+// NOCHAIN: the kernels of levels 12 / 32 / 33 (nochain.h:146-318: one candidate per search, lz_nc_search) — kernels of their own so
+// that neither side carries the other's registers (the hashChain kernels spill already).
+template <bool NOCHAIN>
 LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const LzHc& hc, LzStreams& st)
 {
     const u32 lane = lz_lane();
@@ -661,6 +682,12 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const Lz
     // The first-search results of 128 positions (best[bwBase + lane], best[bwBase + 64 + lane]) ride in two registers: one coalesced
     // trip per 128 positions instead of a dependent one per sequence.
     u32 bwBase = 0xFFFF0000u, bwA = 0, bwB = 0;
+    // noChain levels: the chain words of 128 positions ride in two registers the same way (lz_nc_search)
+    u32 cwBase = 0xFFFF0000u, cwA = 0, cwB = 0;
+    auto ncWord = [&](u32 X) -> u32 {
+        const u32 o = X - cwBase;
+        return o < 64u ? lz_readlane(cwA, o) : o < 128u ? lz_readlane(cwB, o - 64u) : lz_uniform(hc.chain2[X]);
+    };
     for (;;) {
         // ---------------- :204-206: first position with any match: a scan of the hit bits ----------------
         for (;;) {
@@ -675,7 +702,7 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const Lz
         LZ_PROF(st, 0);
         {
             u32 bw = LZ_HC_BEST_OPEN;                            // the first search, decided ahead of the parse
-            if (LZ_HC_PREPASS && hc.pre) {
+            if (!NOCHAIN && LZ_HC_PREPASS && hc.pre) {
                 if ((u32)ip - bwBase >= 128u) {
                     bwBase = (u32)ip & ~63u;
                     const u32 last = nBlock - 1u, ia = bwBase + lane, ib = bwBase + 64u + lane;
@@ -685,6 +712,14 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const Lz
                 bw = o < 64u ? lz_readlane(bwA, o) : lz_readlane(bwB, o - 64u);
             }
             if (bw != LZ_HC_BEST_OPEN) { LZ_STAT(19); ml = (int)(bw & 0xFFFFu); ref = (u32)ip - (bw >> 16); }
+            else if constexpr (NOCHAIN) {
+                if ((u32)ip - cwBase >= 128u) {
+                    cwBase = (u32)ip & ~63u;
+                    const u32 last = nBlock - 1u, ia = cwBase + lane, ib = cwBase + 64u + lane;
+                    cwA = hc.chain2[ia < last ? ia : last]; cwB = hc.chain2[ib < last ? ib : last];
+                }
+                ml = (int)lz_nc_search(src, ncWord((u32)ip), (u32)ip, (u32)ip, (u32)matchlimit, 0u, false, ref, dummy);
+            }
             else { LZ_STAT(20); ml = (int)lz_hc_search(src, nBlock, hc, (u32)ip, (u32)ip, (u32)matchlimit, 0u, false, ref, dummy, st); }
         }
         LZ_PROF(st, 1);
@@ -693,7 +728,8 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const Lz
     search2:
         if (ip + ml < mflimit) LZ_STAT(21);
         if (ip + ml < mflimit && (!LZ_HC_SKIP_NOHIT || lz_hc_hit_at(hc, bm, bmBase, (u32)(ip + ml - 2))))   // :212-214
-            { LZ_STAT(22); ml2 = (int)lz_hc_search(src, nBlock, hc, (u32)(ip + ml - 2), (u32)(ip + 1), (u32)matchlimit, (u32)ml, true, ref2, start2, st); }
+            { LZ_STAT(22); ml2 = NOCHAIN ? (int)lz_nc_search(src, ncWord((u32)(ip + ml - 2)), (u32)(ip + ml - 2), (u32)(ip + 1), (u32)matchlimit, (u32)ml, true, ref2, start2)
+                                            : (int)lz_hc_search(src, nBlock, hc, (u32)(ip + ml - 2), (u32)(ip + 1), (u32)matchlimit, (u32)ml, true, ref2, start2, st); }
         else ml2 = ml;
         LZ_PROF(st, 2);
         if (ml2 == ml) {                                                                          // :216-219
@@ -713,7 +749,7 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const Lz
             if (new_ml > LZ_HC_OPTIMAL_ML) new_ml = LZ_HC_OPTIMAL_ML;
             if (ip + new_ml > (int)start2 + ml2 - 4) {
                 new_ml = (int)start2 - ip + ml2 - 4;
-                if (new_ml < 4 && !hc.noChain) {                                                  // hashchain.h:257-260; nochain.h:210 has no such exit
+                if (new_ml < 4 && !NOCHAIN) {                                                  // hashchain.h:257-260; nochain.h:210 has no such exit
                     lz_seq_push(st, (u32)(ip - anchor), (u32)ml, (u32)ip - ref); ip += ml; anchor = ip;
                     continue;
                 }
@@ -723,7 +759,8 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const Lz
         }
         if ((int)start2 + ml2 < mflimit) LZ_STAT(23);
         if ((int)start2 + ml2 < mflimit && (!LZ_HC_SKIP_NOHIT || lz_hc_hit_at(hc, bm, bmBase, start2 + (u32)ml2 - 3u)))   // :263-265
-            { LZ_STAT(24); ml3 = (int)lz_hc_search(src, nBlock, hc, start2 + (u32)ml2 - 3u, start2, (u32)matchlimit, (u32)ml2, true, ref3, start3, st); }
+            { LZ_STAT(24); ml3 = NOCHAIN ? (int)lz_nc_search(src, ncWord(start2 + (u32)ml2 - 3u), start2 + (u32)ml2 - 3u, start2, (u32)matchlimit, (u32)ml2, true, ref3, start3)
+                                            : (int)lz_hc_search(src, nBlock, hc, start2 + (u32)ml2 - 3u, start2, (u32)matchlimit, (u32)ml2, true, ref3, start3, st); }
         else ml3 = ml2;
         LZ_PROF(st, 3);
         if (ml3 == ml2) {                                                                         // :267-275

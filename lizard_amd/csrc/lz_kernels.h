@@ -198,7 +198,8 @@ __global__ __launch_bounds__(64 * LZ_WAVES_FAST18) void lz_fast18_kernel(LzBatch
 // levels 13-17 / 34-38: hashChain parser (searchLength 5 for rows 13-15, 4 for 16-17; searchNum comes from the
 // level at run time).  Per wave: bins + chain array in global memory, Huffman workspace in LDS; the chain build of a
 // block borrows one of LZ_HC_POOL 32 KiB LDS regions of the workgroup.
-// levels 12 / 33 (noChain, hashLog 18) run the <*, 5, 18> kernels with searchNum 1; level 32 (hashLog 14) is <true, 5, 14>.
+// levels 12 / 33 (noChain, hashLog 18) are <*, 6, 18> — hash5, one candidate per search, searches of one memory trip — and level 32
+// (hashLog 14) is <true, 6, 14>.
 #ifndef LZ_WAVES_HC
 #define LZ_WAVES_HC 16
 #endif

@@ -73,8 +73,8 @@ extern "C" int emul_compress_block(const void* src, int n, void* dst, int level,
     if (a.wideOcc) memset(a.wideOcc, 0x77, 8192 + 8);
     a.hcRegion = (u32*)aligned_alloc(64, 4 * LZ_HC_REGION_WORDS + 64);
     memset(a.hcRegion, 0x3C, 4 * LZ_HC_REGION_WORDS);
-    if (level == 32) lzemu::run_wave(entry_block<LZ_PARSER_HASHCHAIN, 14, 5, true>, &a, seed);
-    else if (ncLevel) lzemu::run_wave(huf ? entry_block<LZ_PARSER_HASHCHAIN, 18, 5, true> : entry_block<LZ_PARSER_HASHCHAIN, 18, 5, false>, &a, seed);
+    if (level == 32) lzemu::run_wave(entry_block<LZ_PARSER_HASHCHAIN, 14, 6, true>, &a, seed);
+    else if (ncLevel) lzemu::run_wave(huf ? entry_block<LZ_PARSER_HASHCHAIN, 18, 6, true> : entry_block<LZ_PARSER_HASHCHAIN, 18, 6, false>, &a, seed);
     else switch (base) {
     case 13: case 14: case 15: lzemu::run_wave(huf ? entry_block<LZ_PARSER_HASHCHAIN, 18, 5, true> : entry_block<LZ_PARSER_HASHCHAIN, 18, 5, false>, &a, seed); break;
     case 16: case 17:          lzemu::run_wave(huf ? entry_block<LZ_PARSER_HASHCHAIN, 18, 4, true> : entry_block<LZ_PARSER_HASHCHAIN, 18, 4, false>, &a, seed); break;
