@@ -651,6 +651,47 @@ LZ_DEV u32 lz_nc_search(const u8* src, u32 cw, u32 X, u32 iLow, u32 iHigh, u32 l
     return longest;
 }
 
+// One search at searchNum 2 (levels 13 / 34; hashchain.h:45-107 / :109-185 with two attempts): both candidates come out of X's
+// chain word (prev | two links at once << 16), and they are measured side by side — lanes 0..31 on the first, lanes 32..63 on the
+// second: 256 bytes forward (8 per lane) and 32 backward (one per lane) each, ONE memory trip where the general search walks, tests
+// 4 bytes and measures in three.  The hit bit (read first by every caller) says that at least one of them passes the 4-byte test; the
+// other one costs loads that run beside it, not a trip.  "First strictly longer in chain order" = the first candidate unless the
+// second is strictly longer.
+LZ_DEV u32 lz_hc2_search(const u8* src, u32 cw, u32 X, u32 iLow, u32 iHigh, u32 longest, bool wider, u32& ref, u32& start)
+{
+    const u32 lane = lz_lane(), half = lane >> 5, li = lane & 31u;
+    const u32 d1 = cw & 0xFFFFu, d2 = cw >> 16;                  // uniform; d2 = 0: no second candidate inside any window
+    if (!d1) return longest;                                     // :70 / :138 no head inside the window
+    const u32 d = half ? d2 : d1;
+    const bool live = d >= LZ_MIN_OFFSET;                        // :75 / :143 (a missing second candidate has d = 0)
+    const u32 m = X - (live ? d : 0u);
+    const u32 i = 8u * li, j = li + 1u;
+    const bool inF = live && X + i < iHigh, inB = live && wider && X >= iLow + j && m >= j;
+    const u64 x = lz_ld64(src + (inF ? X + i : X)) ^ lz_ld64(src + (inF ? m + i : X));
+    const u32 bp = src[inB ? X - j : X], bm = src[inB ? m - j : X];
+    u32 c = 0;
+    if (inF) { const u32 room = iHigh - (X + i); c = x ? lz_ctz64(x) >> 3 : 8u; c = c < room ? c : room; }
+    lz_converge();
+    const u64 stop = lz_ballot(c < 8u), ne = lz_ballot(!(inB && bp == bm));
+    u32 f[2], b[2];
+    #pragma unroll
+    for (u32 k = 0; k < 2u; k++) {
+        const u32 dk = k ? d2 : d1, mk = X - dk;
+        const u32 s32 = (u32)(stop >> (32u * k)), n32 = (u32)(ne >> (32u * k));
+        if (dk < LZ_MIN_OFFSET) { f[k] = 0; b[k] = 0; continue; }
+        if (s32) { const u32 t = (u32)__builtin_ctz(s32); f[k] = 8u * t + lz_readlane(c, 32u * k + t); }
+        else f[k] = 256u + lz_count_fwd(src, X + 256u, mk + 256u, iHigh);
+        if (n32) b[k] = (u32)__builtin_ctz(n32);
+        else b[k] = 32u + lz_count_back(src, X - 32u, mk - 32u, iLow);
+    }
+    #pragma unroll
+    for (u32 k = 0; k < 2u; k++) {                               // chain order: the first candidate, then the second
+        const u32 dk = k ? d2 : d1;
+        if (f[k] >= 4u && f[k] + b[k] > longest) { longest = f[k] + b[k]; ref = X - dk - b[k]; start = X - b[k]; }     // :73-80 / :146-158
+    }
+    return longest;
+}
+
 // The hit bit of position X (uniform): out of the 4 096 positions of bits the outer loop holds in registers when X lies there,
 // else one word from memory.  A search at a position whose bit is clear — the first one or a "wider" one (hashchain.h:45-107,
 // :109-186: both test the 4 bytes AT the position, :73 / :146) — finds nothing: no walk, no candidate bytes, no memory trip.
@@ -667,11 +708,13 @@ LZ_DEV bool lz_hc_hit_at(const LzHc& hc, u64 bm, u32 bmBase, u32 X)
 }
 
 // Sub-block [S,E) of the block at src (hashchain.h:188-369).  The chain must have been built for the block.
-// NOCHAIN: the kernels of levels 12 / 32 / 33 (nochain.h:146-318: one candidate per search, lz_nc_search) — kernels of their own so
-// that neither side carries the other's registers (the hashChain kernels spill already).
-template <bool NOCHAIN>
+// NCAND 1: the kernels of levels 12 / 32 / 33 (nochain.h:146-318: one candidate per search, lz_nc_search); NCAND 2: levels 13 / 34
+// (searchNum 2: both candidates out of one chain word, lz_hc2_search); NCAND 0: the chain walk of lz_hc_search.  Kernels of their own so
+// that no side carries another's registers (the hashChain kernels spill already).
+template <int NCAND>
 LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const LzHc& hc, LzStreams& st)
 {
+    constexpr bool NOCHAIN = NCAND == 1;
     const u32 lane = lz_lane();
     int anchor = (int)S, ip = (int)S + 1;                        // uniform; :201
     const int mflimit = (int)E - (int)LZ_MFLIMIT, matchlimit = (int)E - (int)LZ_LASTLITERALS;
@@ -712,13 +755,15 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const Lz
                 bw = o < 64u ? lz_readlane(bwA, o) : lz_readlane(bwB, o - 64u);
             }
             if (bw != LZ_HC_BEST_OPEN) { LZ_STAT(19); ml = (int)(bw & 0xFFFFu); ref = (u32)ip - (bw >> 16); }
-            else if constexpr (NOCHAIN) {
+            else if constexpr (NCAND != 0) {
+                LZ_STAT(20);
                 if ((u32)ip - cwBase >= 128u) {
                     cwBase = (u32)ip & ~63u;
                     const u32 last = nBlock - 1u, ia = cwBase + lane, ib = cwBase + 64u + lane;
                     cwA = hc.chain2[ia < last ? ia : last]; cwB = hc.chain2[ib < last ? ib : last];
                 }
-                ml = (int)lz_nc_search(src, ncWord((u32)ip), (u32)ip, (u32)ip, (u32)matchlimit, 0u, false, ref, dummy);
+                if constexpr (NCAND == 1) ml = (int)lz_nc_search(src, ncWord((u32)ip), (u32)ip, (u32)ip, (u32)matchlimit, 0u, false, ref, dummy);
+                else                      ml = (int)lz_hc2_search(src, ncWord((u32)ip), (u32)ip, (u32)ip, (u32)matchlimit, 0u, false, ref, dummy);
             }
             else { LZ_STAT(20); ml = (int)lz_hc_search(src, nBlock, hc, (u32)ip, (u32)ip, (u32)matchlimit, 0u, false, ref, dummy, st); }
         }
@@ -728,7 +773,8 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const Lz
     search2:
         if (ip + ml < mflimit) LZ_STAT(21);
         if (ip + ml < mflimit && (!LZ_HC_SKIP_NOHIT || lz_hc_hit_at(hc, bm, bmBase, (u32)(ip + ml - 2))))   // :212-214
-            { LZ_STAT(22); ml2 = NOCHAIN ? (int)lz_nc_search(src, ncWord((u32)(ip + ml - 2)), (u32)(ip + ml - 2), (u32)(ip + 1), (u32)matchlimit, (u32)ml, true, ref2, start2)
+            { LZ_STAT(22); ml2 = NCAND == 1 ? (int)lz_nc_search(src, ncWord((u32)(ip + ml - 2)), (u32)(ip + ml - 2), (u32)(ip + 1), (u32)matchlimit, (u32)ml, true, ref2, start2)
+                                 : NCAND == 2 ? (int)lz_hc2_search(src, ncWord((u32)(ip + ml - 2)), (u32)(ip + ml - 2), (u32)(ip + 1), (u32)matchlimit, (u32)ml, true, ref2, start2)
                                             : (int)lz_hc_search(src, nBlock, hc, (u32)(ip + ml - 2), (u32)(ip + 1), (u32)matchlimit, (u32)ml, true, ref2, start2, st); }
         else ml2 = ml;
         LZ_PROF(st, 2);
@@ -759,7 +805,8 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const Lz
         }
         if ((int)start2 + ml2 < mflimit) LZ_STAT(23);
         if ((int)start2 + ml2 < mflimit && (!LZ_HC_SKIP_NOHIT || lz_hc_hit_at(hc, bm, bmBase, start2 + (u32)ml2 - 3u)))   // :263-265
-            { LZ_STAT(24); ml3 = NOCHAIN ? (int)lz_nc_search(src, ncWord(start2 + (u32)ml2 - 3u), start2 + (u32)ml2 - 3u, start2, (u32)matchlimit, (u32)ml2, true, ref3, start3)
+            { LZ_STAT(24); ml3 = NCAND == 1 ? (int)lz_nc_search(src, ncWord(start2 + (u32)ml2 - 3u), start2 + (u32)ml2 - 3u, start2, (u32)matchlimit, (u32)ml2, true, ref3, start3)
+                                 : NCAND == 2 ? (int)lz_hc2_search(src, ncWord(start2 + (u32)ml2 - 3u), start2 + (u32)ml2 - 3u, start2, (u32)matchlimit, (u32)ml2, true, ref3, start3)
                                             : (int)lz_hc_search(src, nBlock, hc, start2 + (u32)ml2 - 3u, start2, (u32)matchlimit, (u32)ml2, true, ref3, start3, st); }
         else ml3 = ml2;
         LZ_PROF(st, 3);
