@@ -94,7 +94,7 @@ def kernel_name(level, bs):
         return "lz_hashchain_kernel<true, 6, 14>"
     if level in (12, 33):
         return "lz_hashchain_kernel<%s, 6, 18>" % huf
-    return "lz_hashchain_kernel<%s, %d, 18>" % (huf, 7 if base == 13 else 5 if base <= 15 else 4)
+    return "lz_hashchain_kernel<%s, %d, 18>" % (huf, 7 if base == 13 else 8 if base == 14 else 9 if base == 15 else 4)
 
 
 def kernel_source_sha16():

@@ -455,12 +455,14 @@ int launch(Ctx& c, const void* d_src, size_t nBlocks, size_t blockSize, size_t l
     case 31: hipLaunchKernelGGL(lz_fast18_kernel<true>, g, t, 0, stream, a); break;
     case 12:                   hipLaunchKernelGGL((lz_hashchain_kernel<false, 6>), g, t, 0, stream, a); break;
     case 13:                   hipLaunchKernelGGL((lz_hashchain_kernel<false, 7>), g, t, 0, stream, a); break;
-    case 14: case 15:          hipLaunchKernelGGL((lz_hashchain_kernel<false, 5>), g, t, 0, stream, a); break;
+    case 14:                   hipLaunchKernelGGL((lz_hashchain_kernel<false, 8>), g, t, 0, stream, a); break;
+    case 15:                   hipLaunchKernelGGL((lz_hashchain_kernel<false, 9>), g, t, 0, stream, a); break;
     case 16: case 17:          hipLaunchKernelGGL((lz_hashchain_kernel<false, 4>), g, t, 0, stream, a); break;
     case 32:                   hipLaunchKernelGGL((lz_hashchain_kernel<true, 6, 14>), g, t, 0, stream, a); break;
     case 33:                   hipLaunchKernelGGL((lz_hashchain_kernel<true, 6>), g, t, 0, stream, a); break;
     case 34:                   hipLaunchKernelGGL((lz_hashchain_kernel<true, 7>), g, t, 0, stream, a); break;
-    case 35: case 36:          hipLaunchKernelGGL((lz_hashchain_kernel<true, 5>), g, t, 0, stream, a); break;
+    case 35:                   hipLaunchKernelGGL((lz_hashchain_kernel<true, 8>), g, t, 0, stream, a); break;
+    case 36:                   hipLaunchKernelGGL((lz_hashchain_kernel<true, 9>), g, t, 0, stream, a); break;
     case 37: case 38:          hipLaunchKernelGGL((lz_hashchain_kernel<true, 4>), g, t, 0, stream, a); break;
     case 20: hipLaunchKernelGGL(lz_fastbig14_kernel<false>, g, t, 0, stream, a); break;
     case 40: hipLaunchKernelGGL(lz_fastbig14_kernel<true>, g, t, 0, stream, a); break;

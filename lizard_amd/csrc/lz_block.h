@@ -932,9 +932,9 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
         const bool noChain = level == 12u || level == 32u || level == 33u;           // :239, :262-263: one candidate per search
         lz_hc_begin(hc, tableMem, maxBlock, noChain ? 1u : row == 4u ? 256u : 2u << row);
         hc.noChain = noChain;
-        // AUX: the level's searchLength (4 or 5), or 6 = the kernels of the noChain levels (hash5, nochain.h:4), or 7 = the kernels of
-        // levels 13 / 34 (hash5, searchNum 2: lz_hc2_search)
-        static_assert(AUX >= 4 && AUX <= 7, "hashChain: searchLength 4 / 5, 6 = noChain, 7 = searchNum 2");
+        // AUX: the level's searchLength (4 or 5), or 6 = the kernels of the noChain levels (hash5, nochain.h:4), or 7 / 8 / 9 = the
+        // kernels of levels 13 / 14 / 15 and twins (hash5, searchNum 2 / 4 / 8: lz_hcN_search)
+        static_assert(AUX >= 4 && AUX <= 9, "hashChain: searchLength 4 / 5, 6 = noChain, 7 / 8 / 9 = searchNum 2 / 4 / 8");
         lz_hc_build<(AUX >= 6 ? 5 : AUX), HASHLOG>(src, n, hc, *hcPool, st);
         // first searches decided ahead of the parse at levels 16/17 / 37/38 (searchLength 4: searchNum 16 / 256, three times the
         // sequences of level 13); at 13-15 the plain hit pass is the faster one (profiles/r04y_*)
@@ -963,7 +963,7 @@ LZ_DEV u32 lz_compress_block(const u8* src, u32 n, u8* dst, u32 level, void* tab
         const u32 part = (n - pos) < LZ_SUBBLOCK ? (n - pos) : LZ_SUBBLOCK;
         st.nlit = st.nflags = st.noff16 = st.noff24 = 0;      // Lizard_initBlock, :130-138
         st.nseq = 0; st.lastLits = 0;
-        if constexpr (PARSER == LZ_PARSER_HASHCHAIN) lz_parse_hashchain<(AUX == 6 ? 1 : AUX == 7 ? 2 : 0)>(src, n, pos, pos + part, hc, st);
+        if constexpr (PARSER == LZ_PARSER_HASHCHAIN) lz_parse_hashchain<(AUX == 6 ? 1 : AUX == 7 ? 2 : AUX == 8 ? 4 : AUX == 9 ? 8 : 0)>(src, n, pos, pos + part, hc, st);
         else if constexpr (PARSER == LZ_PARSER_FASTBIG) lz_parse_fastbig<HASHLOG, AUX>(src, pos, pos + part, pf32g, ws, wideOcc, st);
         else if constexpr (kWide)                    lz_parse_fast<HASHLOG>(src, pos, pos + part, tabw, st);
         else if constexpr (PARSER == LZ_PARSER_FAST) {

@@ -651,43 +651,62 @@ LZ_DEV u32 lz_nc_search(const u8* src, u32 cw, u32 X, u32 iLow, u32 iHigh, u32 l
     return longest;
 }
 
-// One search at searchNum 2 (levels 13 / 34; hashchain.h:45-107 / :109-185 with two attempts): both candidates come out of X's
-// chain word (prev | two links at once << 16), and they are measured side by side — lanes 0..31 on the first, lanes 32..63 on the
-// second: 256 bytes forward (8 per lane) and 32 backward (one per lane) each, ONE memory trip where the general search walks, tests
-// 4 bytes and measures in three.  The hit bit (read first by every caller) says that at least one of them passes the 4-byte test; the
-// other one costs loads that run beside it, not a trip.  "First strictly longer in chain order" = the first candidate unless the
-// second is strictly longer.
-LZ_DEV u32 lz_hc2_search(const u8* src, u32 cw, u32 X, u32 iLow, u32 iHigh, u32 longest, bool wider, u32& ref, u32& start)
+// One search at searchNum NC = 2 / 4 / 8 (levels 13 / 14 / 15 and 34 / 35 / 36; hashchain.h:45-107 / :109-185 with NC attempts): the
+// candidates come out of packed chain words (prev | two links at once << 16: two candidates per word; the first word is X's, out of
+// the parse's register window), and all of them are measured side by side — 64 / NC lanes each, 8 bytes forward and one byte backward
+// per lane — in ONE memory trip behind the walk's NC / 2 - 1 dependent words, where the general search walks, tests 4 bytes and measures
+// one after the other.  The hit bit (read first by every caller) says that at least one of them passes the 4-byte test; the others
+// cost loads that run beside it, not trips.  "First strictly longer in chain order" = candidates in order, strictly longer wins.
+template <int NC>
+LZ_DEV u32 lz_hcN_search(const u8* src, const LzHc& hc, u32 cw, u32 X, u32 iLow, u32 iHigh, u32 longest, bool wider, u32& ref, u32& start)
 {
-    const u32 lane = lz_lane(), half = lane >> 5, li = lane & 31u;
-    const u32 d1 = cw & 0xFFFFu, d2 = cw >> 16;                  // uniform; d2 = 0: no second candidate inside any window
-    if (!d1) return longest;                                     // :70 / :138 no head inside the window
-    const u32 d = half ? d2 : d1;
-    const bool live = d >= LZ_MIN_OFFSET;                        // :75 / :143 (a missing second candidate has d = 0)
+    static_assert(NC == 2 || NC == 4 || NC == 8, "two candidates per chain word; 64 / NC lanes per candidate");
+    constexpr u32 G = 64u / NC;                                  // lanes per candidate
+    const u32 lane = lz_lane(), k = lane / G, li = lane % G;
+    // the walk (uniform): distance of candidate c from X, 0 = none (and none behind it): hashchain.h:70 / :100-102 per step
+    u32 dist[NC];
+    {
+        u32 base = 0, w = cw;
+        bool more = true;
+        #pragma unroll
+        for (u32 c = 0; c < (u32)NC; c += 2u) {
+            u32 a = 0, b2 = 0;
+            if (more) {
+                const u32 e1 = w & 0xFFFFu, e2 = w >> 16;
+                if (e1 && base + e1 <= LZ_MAX_DIST_LZ4) { a = base + e1; if (e2 && base + e2 <= LZ_MAX_DIST_LZ4) b2 = base + e2; }
+                more = b2 != 0u;
+                if (c + 2u < (u32)NC && more) { w = lz_uniform(hc.chain2[X - b2]); base = b2; }
+            }
+            dist[c] = a; dist[c + 1u] = b2;
+        }
+    }
+    if (!dist[0]) return longest;                                // no head inside the window
+    u32 d = 0;
+    #pragma unroll
+    for (u32 c = 0; c < (u32)NC; c++) d = k == c ? dist[c] : d;
+    const bool live = d >= LZ_MIN_OFFSET;                        // :75 / :143 (a missing candidate has d = 0)
     const u32 m = X - (live ? d : 0u);
     const u32 i = 8u * li, j = li + 1u;
     const bool inF = live && X + i < iHigh, inB = live && wider && X >= iLow + j && m >= j;
     const u64 x = lz_ld64(src + (inF ? X + i : X)) ^ lz_ld64(src + (inF ? m + i : X));
     const u32 bp = src[inB ? X - j : X], bm = src[inB ? m - j : X];
-    u32 c = 0;
-    if (inF) { const u32 room = iHigh - (X + i); c = x ? lz_ctz64(x) >> 3 : 8u; c = c < room ? c : room; }
+    u32 cq = 0;
+    if (inF) { const u32 room = iHigh - (X + i); cq = x ? lz_ctz64(x) >> 3 : 8u; cq = cq < room ? cq : room; }
     lz_converge();
-    const u64 stop = lz_ballot(c < 8u), ne = lz_ballot(!(inB && bp == bm));
-    u32 f[2], b[2];
+    const u64 stop = lz_ballot(cq < 8u), ne = lz_ballot(!(inB && bp == bm));
     #pragma unroll
-    for (u32 k = 0; k < 2u; k++) {
-        const u32 dk = k ? d2 : d1, mk = X - dk;
-        const u32 s32 = (u32)(stop >> (32u * k)), n32 = (u32)(ne >> (32u * k));
-        if (dk < LZ_MIN_OFFSET) { f[k] = 0; b[k] = 0; continue; }
-        if (s32) { const u32 t = (u32)__builtin_ctz(s32); f[k] = 8u * t + lz_readlane(c, 32u * k + t); }
-        else f[k] = 256u + lz_count_fwd(src, X + 256u, mk + 256u, iHigh);
-        if (n32) b[k] = (u32)__builtin_ctz(n32);
-        else b[k] = 32u + lz_count_back(src, X - 32u, mk - 32u, iLow);
-    }
-    #pragma unroll
-    for (u32 k = 0; k < 2u; k++) {                               // chain order: the first candidate, then the second
-        const u32 dk = k ? d2 : d1;
-        if (f[k] >= 4u && f[k] + b[k] > longest) { longest = f[k] + b[k]; ref = X - dk - b[k]; start = X - b[k]; }     // :73-80 / :146-158
+    for (u32 c = 0; c < (u32)NC; c++) {                          // chain order
+        const u32 dc = dist[c];
+        if (dc < LZ_MIN_OFFSET) continue;                        // uniform
+        const u32 mc = X - dc;
+        const u32 sf = (u32)(stop >> (G * c)) & (u32)((1ull << G) - 1ull), nf = (u32)(ne >> (G * c)) & (u32)((1ull << G) - 1ull);
+        u32 f, b;
+        if (sf) { const u32 t = (u32)__builtin_ctz(sf); f = 8u * t + lz_readlane(cq, G * c + t); }
+        else f = 8u * G + lz_count_fwd(src, X + 8u * G, mc + 8u * G, iHigh);
+        if (f < 4u) continue;                                    // :73 / :146
+        if (nf) b = (u32)__builtin_ctz(nf);
+        else b = G + lz_count_back(src, X - G, mc - G, iLow);
+        if (f + b > longest) { longest = f + b; ref = mc - b; start = X - b; }      // :76-80 / :150-158
     }
     return longest;
 }
@@ -708,9 +727,10 @@ LZ_DEV bool lz_hc_hit_at(const LzHc& hc, u64 bm, u32 bmBase, u32 X)
 }
 
 // Sub-block [S,E) of the block at src (hashchain.h:188-369).  The chain must have been built for the block.
-// NCAND 1: the kernels of levels 12 / 32 / 33 (nochain.h:146-318: one candidate per search, lz_nc_search); NCAND 2: levels 13 / 34
-// (searchNum 2: both candidates out of one chain word, lz_hc2_search); NCAND 0: the chain walk of lz_hc_search.  Kernels of their own so
-// that no side carries another's registers (the hashChain kernels spill already).
+// NCAND 1: the kernels of levels 12 / 32 / 33 (nochain.h:146-318: one candidate per search, lz_nc_search); NCAND 2 / 4 / 8: levels
+// 13 / 14 / 15 and twins (searchNum = NCAND: the candidates measured side by side, lz_hcN_search); NCAND 0: the chain walk of
+// lz_hc_search (levels 16 / 17: 16 / 256 candidates).  Kernels of their own so that no side carries another's registers (the hashChain
+// kernels spill already).
 template <int NCAND>
 LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const LzHc& hc, LzStreams& st)
 {
@@ -763,7 +783,7 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const Lz
                     cwA = hc.chain2[ia < last ? ia : last]; cwB = hc.chain2[ib < last ? ib : last];
                 }
                 if constexpr (NCAND == 1) ml = (int)lz_nc_search(src, ncWord((u32)ip), (u32)ip, (u32)ip, (u32)matchlimit, 0u, false, ref, dummy);
-                else                      ml = (int)lz_hc2_search(src, ncWord((u32)ip), (u32)ip, (u32)ip, (u32)matchlimit, 0u, false, ref, dummy);
+                else                      ml = (int)lz_hcN_search<(NCAND > 1 ? NCAND : 2)>(src, hc, ncWord((u32)ip), (u32)ip, (u32)ip, (u32)matchlimit, 0u, false, ref, dummy);
             }
             else { LZ_STAT(20); ml = (int)lz_hc_search(src, nBlock, hc, (u32)ip, (u32)ip, (u32)matchlimit, 0u, false, ref, dummy, st); }
         }
@@ -774,7 +794,7 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const Lz
         if (ip + ml < mflimit) LZ_STAT(21);
         if (ip + ml < mflimit && (!LZ_HC_SKIP_NOHIT || lz_hc_hit_at(hc, bm, bmBase, (u32)(ip + ml - 2))))   // :212-214
             { LZ_STAT(22); ml2 = NCAND == 1 ? (int)lz_nc_search(src, ncWord((u32)(ip + ml - 2)), (u32)(ip + ml - 2), (u32)(ip + 1), (u32)matchlimit, (u32)ml, true, ref2, start2)
-                                 : NCAND == 2 ? (int)lz_hc2_search(src, ncWord((u32)(ip + ml - 2)), (u32)(ip + ml - 2), (u32)(ip + 1), (u32)matchlimit, (u32)ml, true, ref2, start2)
+                                 : NCAND > 1 ? (int)lz_hcN_search<(NCAND > 1 ? NCAND : 2)>(src, hc, ncWord((u32)(ip + ml - 2)), (u32)(ip + ml - 2), (u32)(ip + 1), (u32)matchlimit, (u32)ml, true, ref2, start2)
                                             : (int)lz_hc_search(src, nBlock, hc, (u32)(ip + ml - 2), (u32)(ip + 1), (u32)matchlimit, (u32)ml, true, ref2, start2, st); }
         else ml2 = ml;
         LZ_PROF(st, 2);
@@ -806,7 +826,7 @@ LZ_DEV void lz_parse_hashchain(const u8* src, u32 nBlock, u32 S, u32 E, const Lz
         if ((int)start2 + ml2 < mflimit) LZ_STAT(23);
         if ((int)start2 + ml2 < mflimit && (!LZ_HC_SKIP_NOHIT || lz_hc_hit_at(hc, bm, bmBase, start2 + (u32)ml2 - 3u)))   // :263-265
             { LZ_STAT(24); ml3 = NCAND == 1 ? (int)lz_nc_search(src, ncWord(start2 + (u32)ml2 - 3u), start2 + (u32)ml2 - 3u, start2, (u32)matchlimit, (u32)ml2, true, ref3, start3)
-                                 : NCAND == 2 ? (int)lz_hc2_search(src, ncWord(start2 + (u32)ml2 - 3u), start2 + (u32)ml2 - 3u, start2, (u32)matchlimit, (u32)ml2, true, ref3, start3)
+                                 : NCAND > 1 ? (int)lz_hcN_search<(NCAND > 1 ? NCAND : 2)>(src, hc, ncWord(start2 + (u32)ml2 - 3u), start2 + (u32)ml2 - 3u, start2, (u32)matchlimit, (u32)ml2, true, ref3, start3)
                                             : (int)lz_hc_search(src, nBlock, hc, start2 + (u32)ml2 - 3u, start2, (u32)matchlimit, (u32)ml2, true, ref3, start3, st); }
         else ml3 = ml2;
         LZ_PROF(st, 3);

@@ -199,7 +199,8 @@ __global__ __launch_bounds__(64 * LZ_WAVES_FAST18) void lz_fast18_kernel(LzBatch
 // level at run time).  Per wave: bins + chain array in global memory, Huffman workspace in LDS; the chain build of a
 // block borrows one of LZ_HC_POOL 32 KiB LDS regions of the workgroup.
 // levels 12 / 33 (noChain, hashLog 18) are <*, 6, 18> — hash5, one candidate per search, searches of one memory trip — and level 32
-// (hashLog 14) is <true, 6, 14>; levels 13 / 34 (searchNum 2) are <*, 7, 18>: both candidates measured side by side in one trip.
+// (hashLog 14) is <true, 6, 14>; levels 13 / 14 / 15 and twins (searchNum 2 / 4 / 8) are <*, 7 / 8 / 9, 18>: the candidates measured side
+// by side in one trip.
 #ifndef LZ_WAVES_HC
 #define LZ_WAVES_HC 16
 #endif

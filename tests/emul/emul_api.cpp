@@ -77,7 +77,8 @@ extern "C" int emul_compress_block(const void* src, int n, void* dst, int level,
     else if (ncLevel) lzemu::run_wave(huf ? entry_block<LZ_PARSER_HASHCHAIN, 18, 6, true> : entry_block<LZ_PARSER_HASHCHAIN, 18, 6, false>, &a, seed);
     else switch (base) {
     case 13:                   lzemu::run_wave(huf ? entry_block<LZ_PARSER_HASHCHAIN, 18, 7, true> : entry_block<LZ_PARSER_HASHCHAIN, 18, 7, false>, &a, seed); break;
-    case 14: case 15:          lzemu::run_wave(huf ? entry_block<LZ_PARSER_HASHCHAIN, 18, 5, true> : entry_block<LZ_PARSER_HASHCHAIN, 18, 5, false>, &a, seed); break;
+    case 14:                   lzemu::run_wave(huf ? entry_block<LZ_PARSER_HASHCHAIN, 18, 8, true> : entry_block<LZ_PARSER_HASHCHAIN, 18, 8, false>, &a, seed); break;
+    case 15:                   lzemu::run_wave(huf ? entry_block<LZ_PARSER_HASHCHAIN, 18, 9, true> : entry_block<LZ_PARSER_HASHCHAIN, 18, 9, false>, &a, seed); break;
     case 16: case 17:          lzemu::run_wave(huf ? entry_block<LZ_PARSER_HASHCHAIN, 18, 4, true> : entry_block<LZ_PARSER_HASHCHAIN, 18, 4, false>, &a, seed); break;
     case 10: lzemu::run_wave(huf ? entry_block<LZ_PARSER_FAST, 12, 0, true> : entry_block<LZ_PARSER_FAST, 12, 0, false>, &a, seed); break;
     case 11: lzemu::run_wave(huf ? entry_block<LZ_PARSER_FAST, 18, 0, true> : entry_block<LZ_PARSER_FAST, 18, 0, false>, &a, seed); break;

@@ -48,7 +48,7 @@ def test_emulated_kernel_long_range(level):
         assert len(out) == g["size"] and util.sha(out) == g["sha256"], (name, level)
 
 
-@pytest.mark.parametrize("level", [13, 16, 17, 35, 12, 32, 33, 34, 14])
+@pytest.mark.parametrize("level", [13, 16, 17, 35, 12, 32, 33, 34, 14, 15, 36])
 def test_emulated_hashchain_vs_oracle(level):
     """hashChain kernel (lz_hashchain.h): both hash lengths, searchNum 2/8/16/256, with and without Huffman; the noChain levels
     12 / 32 / 33 (one candidate per search, hashLog 18 / 14 / 18, lizard_parser_nochain.h) through the same kernels.
