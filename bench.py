@@ -17,7 +17,8 @@ barrier-bracketed timed region of exactly --steps steps, max over ranks.  The sa
 BASELINE configs with the same --steps / --warmup and reports them under "configs": level 21 and level 30 at
 16 384 x 256 KiB (configs[2..3]) and configs[4] in BOTH readings: weak scaling — 6 656 x 4 MiB blocks PER GPU, two per
 table-holding wave — and strong scaling — 4 096 x 4 MiB blocks in the WHOLE job (SURVEY 8d read literally), 4 096 / N per GPU, the
-same 4 096 blocks at every N ("scaling": "strong", "blocks_total"), and — not a BASELINE config — level 20 (fastBig, LIZv1
+same 4 096 blocks at every N ("scaling": "strong", "blocks_total") — the 16 384-block entries also carry "same_inputs_as_headline":
+the same kernel on the headline's 65 536 blocks ("same inputs"; kernel time, N = 1) — and, not a BASELINE config, level 20 (fastBig, LIZv1
 codewords; round 6) at 16 384 x 256 KiB with the same checks; "config1" is configs[0], the reference's own
 CPU-runnable case (64 MiB RDG_genBuffer P50 seed 0 in 256 KiB blocks, programs/bench.c's loop over Lizard_compress).
 Per config:
@@ -630,6 +631,30 @@ def main():
     for level, bs, nb, scaling in plan:
         r, _ = run_config(level, bs, nb, with_cpu, scaling)
         results.append(r)
+
+    # SURVEY 8d gives configs[2..3] (levels 21 / 30) "the same inputs" as configs[1]; the line has carried them at 16 384 blocks per GPU
+    # since round 1 (5 - 6 blocks per block-claiming wave: the end of the launch, where waves run out of blocks one by one, is a
+    # visible part of it).  The same kernels on the headline's 65 536 blocks, kernel time over 3 launches, ride beside each of them.
+    if world == 1 and args.level is None and args.blocks is None and not args.headline_only:
+        nb_h, bs_h = 65536, 262144
+        for r in results[1:] if rank == 0 else []:
+            if r["block_size"] != bs_h or r["blocks_per_gpu"] >= nb_h or r["scaling"] != "weak":
+                continue
+            stride = (api.Lizard_compressBound(bs_h) + 63) & ~63
+            src, dst = src_all[:nb_h * bs_h], dst_all[:nb_h * stride]
+            sizes = torch.zeros(nb_h, dtype=torch.int32, device=dev)
+            tools_datagen.datagen_device(src.data_ptr(), nb_h, bs_h, 0.5, 0.0, 0, ctypes.c_void_p(stream.cuda_stream))
+            ev = []
+            for i in range(4):
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(stream); api.compress_blocks_device(src, bs_h, r["level"], dst=dst, sizes=sizes); e1.record(stream)
+                if i:
+                    ev.append((e0, e1))
+            torch.cuda.synchronize()
+            ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+            r["same_inputs_as_headline"] = {"blocks_per_gpu": nb_h, "value": round(nb_h * bs_h / ms / 1e3, 1), "unit": "MB/s (kernel time)",
+                                            "avg_kernel_ms": round(ms, 3), "launches": len(ev),
+                                            "compressed_bytes": int(sizes.to(torch.int64).sum().item())}
 
     if rank == 0:
         head = results[0]

@@ -35,6 +35,14 @@ for c in cfgs:
     name = kname(grp[0])
     out.writerow([c["workload"], name, len(ms), "%.3f" % (sum(ms) / len(ms)), "%.3f" % min(ms), "%.3f" % max(ms), c["roofline"]["avg_kernel_ms"],
                   grp[0]["Grid_Size_X"], grp[0]["LDS_Block_Size"], grp[0]["VGPR_Count"]])
+for c in cfgs:                                              # the 65 536-block reading of the 16 384-block configurations: 4 launches each, the first untimed
+    e = c.get("same_inputs_as_headline")
+    if not e:
+        continue
+    grp = rows[i + 1:i + 4]; i += 4
+    ms = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in grp]
+    out.writerow(["same inputs as the headline: L%d %d x 262144" % (c["level"], e["blocks_per_gpu"]), kname(grp[0]), len(ms), "%.3f" % (sum(ms) / len(ms)),
+                  "%.3f" % min(ms), "%.3f" % max(ms), e["avg_kernel_ms"], grp[0]["Grid_Size_X"], grp[0]["LDS_Block_Size"], grp[0]["VGPR_Count"]])
 for p in (d.get("blocks_in_flight") or {}).get("curve", []):
     grp = rows[i + 1:i + 3]; i += 3
     ms = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in grp]
