@@ -134,7 +134,7 @@ def test_gpu_roundtrip_device_batches(L):
     data = util.datagen((24 << 20) + 4321, 0.5, 0.0, 71) + bytes(300000) + random.Random(1).randbytes(200000)
     host = np.frombuffer(data, dtype=np.uint8)
     src = torch.from_numpy(host.copy()).cuda()
-    for level in [l for l in (10, 11, 13, 17, 21, 22, 30, 31, 35, 41, 42) if L.LizardGPU_levelSupported(l)]:
+    for level in [l for l in (10, 11, 13, 17, 21, 22, 30, 31, 35, 41, 42, 20, 40, 12, 33) if L.LizardGPU_levelSupported(l)]:
         for bs in (65536, 262144, 1 << 20):
             dst, sizes, stride = api.compress_blocks_device(src, bs, level)
             nb = sizes.numel()
