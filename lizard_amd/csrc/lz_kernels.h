@@ -187,12 +187,17 @@ __global__ __launch_bounds__(64 * (HUF ? LZ_SPLIT_PROD_HUF + LZ_SPLIT_CONS_HUF :
 
 // levels 11 / 31: fast parser, 2^18-slot table (u32 slots, 1 MiB per wave in global memory: L2 / Infinity Cache)
 #define LZ_WAVES_FAST18 16
+#ifndef LZ_WIDE_HUF_POOL
+#define LZ_WIDE_HUF_POOL 4                   // levels 31 / 42: Huffman workspaces from a pool of this many, which leaves room for the 8 KiB summary of levels 11 / 22 (1 KiB tags); 0 = one each, 4 KiB summary
+#endif
 template <bool HUF>
 __global__ __launch_bounds__(64 * LZ_WAVES_FAST18) void lz_fast18_kernel(LzBatch a)
 {
-    // tag array: 1 KiB (with Huffman: the 2 KiB workspace doubles as it); occupancy summary: 8 KiB (4 slots per bit; 4 KiB with Huffman)
-    lz_wave_main<LZ_PARSER_FAST, 18, 0, HUF, LZ_WAVES_FAST18, (HUF ? LZ_HUF_WS_WORDS : (1u << 10) / 4u), 0, LZ_TABKIND_LDS, 0,
-                 (LZ_WIDE_OCC ? (HUF ? 15 : 16) : 0), (HUF ? LZ_WIDE_TAGLOG : 10)>(a);
+    // tag array: 1 KiB; occupancy summary: 8 KiB (4 slots per bit); level 31 borrows its Huffman workspace from a pool (round 6: with one
+    // workspace per wave doubling as a 2 KiB tag array the summary had 4 KiB: 40.9 -> 42.2 GB/s, level 42 32.9 -> 34.1, profiles/r06zq_*)
+    constexpr bool kOwnWs = HUF && !LZ_WIDE_HUF_POOL;
+    lz_wave_main<LZ_PARSER_FAST, 18, 0, HUF, LZ_WAVES_FAST18, (kOwnWs ? LZ_HUF_WS_WORDS : (1u << 10) / 4u), 0, LZ_TABKIND_LDS, (HUF ? LZ_WIDE_HUF_POOL : 0),
+                 (LZ_WIDE_OCC ? (kOwnWs ? 15 : 16) : 0), (kOwnWs ? LZ_WIDE_TAGLOG : 10)>(a);
 }
 
 // levels 13-17 / 34-38: hashChain parser (searchLength 5 for rows 13-15, 4 for 16-17; searchNum comes from the
@@ -284,8 +289,9 @@ template <bool HUF>
 __global__ __launch_bounds__(64 * LZ_PF22_W) void lz_pricefast18_kernel(LzBatch a)
 {
     // tag array 1 KiB (with Huffman: the 2 KiB workspace doubles as it); occupancy summary of the table 8 KiB (4 KiB with Huffman)
-    lz_wave_main<LZ_PARSER_PRICEFAST, 18, (HUF ? LZ_PF_TAGLOG : 10), HUF, LZ_PF22_W, (HUF ? LZ_HUF_WS_WORDS : (1u << 10) / 4u), 0, LZ_TABKIND_LDS, 0,
-                 (LZ_WIDE_OCC ? (HUF ? 15 : 16) : 0)>(a);
+    constexpr bool kOwnWs = HUF && !LZ_WIDE_HUF_POOL;
+    lz_wave_main<LZ_PARSER_PRICEFAST, 18, (kOwnWs ? LZ_PF_TAGLOG : 10), HUF, LZ_PF22_W, (kOwnWs ? LZ_HUF_WS_WORDS : (1u << 10) / 4u), 0, LZ_TABKIND_LDS,
+                 (HUF ? LZ_WIDE_HUF_POOL : 0), (LZ_WIDE_OCC ? (kOwnWs ? 15 : 16) : 0)>(a);
 }
 
 // Decompression: one wave per block, same persistent grid; block b is read from
