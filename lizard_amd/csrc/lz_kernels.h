@@ -89,14 +89,14 @@ __device__ __forceinline__ void lz_wave_main(const LzBatch& a)
     __shared__ u32 hufPool[POOL ? POOL : 1][POOL ? LZ_HUF_WS_WORDS : 1];
     __shared__ u32 hufPoolMask;
     // hashChain: the chain build of a block borrows one of HCPOOL 32 KiB regions (lz_hc_build)
-    constexpr int HCPOOL = PARSER == LZ_PARSER_HASHCHAIN ? (HUF ? LZ_HC_POOL : LZ_HC_POOL + 1) : 0;   // the Huffman workspaces take a region's worth of LDS
+    constexpr int HCPOOL = PARSER == LZ_PARSER_HASHCHAIN ? ((HUF && !POOL) ? LZ_HC_POOL : LZ_HC_POOL + 1) : 0;   // sixteen Huffman workspaces take a region's worth of LDS (a pool of them does not)
     // levels 11 / 31: occupancy summary of the wave's 2^18-slot table (LzTabWide::occ), 2^OCCLOG bits + a spare word
     constexpr u32 kOccWords = OCCLOG ? ((1u << OCCLOG) >> 5) + 1u : 1u;
     __shared__ u32 wideOcc[OCCLOG ? W : 1][kOccWords];
-    static_assert(!(POOL != 0 && HCPOOL != 0), "one pool mask per workgroup");
+    __shared__ u32 hcPoolMask;                                   // (a mask of its own: the hashChain levels with the Huffman stage use both pools)
     __shared__ u32 hcPoolMem[HCPOOL ? HCPOOL : 1][HCPOOL ? LZ_HC_REGION_WORDS : 1];
-    if constexpr (POOL != 0 || HCPOOL != 0) { if (threadIdx.x == 0) hufPoolMask = 0; __syncthreads(); }
-    LzHufPool hcPool; hcPool.base = &hcPoolMem[0][0]; hcPool.mask = &hufPoolMask; hcPool.count = (u32)HCPOOL; hcPool.stride = LZ_HC_REGION_WORDS;
+    if constexpr (POOL != 0 || HCPOOL != 0) { if (threadIdx.x == 0) { hufPoolMask = 0; hcPoolMask = 0; } __syncthreads(); }
+    LzHufPool hcPool; hcPool.base = &hcPoolMem[0][0]; hcPool.mask = &hcPoolMask; hcPool.count = (u32)HCPOOL; hcPool.stride = LZ_HC_REGION_WORDS;
     constexpr u32 kTagWords = (PARSER == LZ_PARSER_FAST ? (1u << LZ_WIDE_TAGLOG) : (1u << AUX)) / 4u;
     __shared__ u32 wideTags[kOwnTags ? W - NLDS : 1][kOwnTags ? kTagWords : 1];
     const u32 wave = lz_uniform(threadIdx.x >> 6);               // readfirstlane: the wave index (and everything derived from it) lives in SGPRs
@@ -209,10 +209,14 @@ __global__ __launch_bounds__(64 * LZ_WAVES_FAST18) void lz_fast18_kernel(LzBatch
 #ifndef LZ_WAVES_HC
 #define LZ_WAVES_HC 16
 #endif
+#ifndef LZ_HC_HUF_POOL
+#define LZ_HC_HUF_POOL 0                     // levels 32-38: Huffman workspaces from a pool of this many — and a fourth chain-build region; 0 = one workspace each, three regions
+#endif
 template <bool HUF, int SEARCHLEN, int HLOG = 18>
 __global__ __launch_bounds__(64 * LZ_WAVES_HC) void lz_hashchain_kernel(LzBatch a)
 {
-    lz_wave_main<LZ_PARSER_HASHCHAIN, HLOG, SEARCHLEN, HUF, LZ_WAVES_HC, (HUF ? LZ_HUF_WS_WORDS : 1), 0>(a);
+    lz_wave_main<LZ_PARSER_HASHCHAIN, HLOG, SEARCHLEN, HUF, LZ_WAVES_HC, ((HUF && !LZ_HC_HUF_POOL) ? LZ_HUF_WS_WORDS : 1), 0, LZ_TABKIND_LDS,
+                 (HUF ? LZ_HC_HUF_POOL : 0)>(a);
 }
 
 // levels 20 / 40: fastBig + LIZv1 (lz_fastbig.h), 2^14 u32 slots per wave in its global-memory slot (the slots of levels 21 / 41);
